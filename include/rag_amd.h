@@ -1,0 +1,138 @@
+/*
+ * rag_amd.h — C ABI of the MI355X-native retrieval hot path.
+ *
+ * The reference (IanHollow/rag-inference-pipeline) has no FFI of its own: its hot path is
+ * three Python components that delegate to third-party native wheels.  This header is the
+ * C-level seam those components bind instead of the wheels.  Each entry point cites the
+ * reference call site it replaces (paths relative to the reference repo root):
+ *
+ *   rag_index_*      <- src/pipeline/components/faiss_store.py
+ *                         load()    :40-111  (faiss.read_index + warm-up search)
+ *                         search()  :113-158 (index.search(embeddings, k) -> (D, I))
+ *                         unload()  :160-171, index_size :178-183
+ *   rag_encoder_*    <- src/pipeline/components/embedding.py
+ *                         load()    :70-98   (SentenceTransformer(name))
+ *                         encode()  :100-175 (model.encode(..., normalize_embeddings=True))
+ *   rag_reranker_*   <- src/pipeline/components/reranker.py
+ *                         load()    :71-173  (AutoModelForSequenceClassification)
+ *                         rerank()  :206-272 (model(**inputs).logits -> sigmoid)
+ *
+ * Conventions
+ *   - Every function returns an int status (RAG_OK == 0) unless documented otherwise; no C++
+ *     exception crosses the boundary.  rag_last_error() returns a thread-local message.
+ *   - Plain pointers and sizes only.  "host" pointers are ordinary process memory; "dev"
+ *     pointers are HIP device memory on the handle's device.  `stream` is a hipStream_t
+ *     passed as void* (NULL = the handle's own stream).
+ *   - Handles are thread-safe: concurrent calls on one handle serialise on an internal mutex
+ *     (the reference's BatchScheduler can have several batches in flight,
+ *     services/gateway/batch_scheduler.py:286-288).
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with RAG_ERR_NO_DEVICE.
+ */
+#ifndef RAG_AMD_H
+#define RAG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAG_AMD_ABI_VERSION 1
+
+/* status codes */
+#define RAG_OK 0
+#define RAG_ERR_INVALID_ARG 1   /* bad pointer / size / k / metric */
+#define RAG_ERR_NO_DEVICE 2     /* no HIP device, or device index out of range */
+#define RAG_ERR_HIP 3           /* a HIP runtime call failed (see rag_last_error) */
+#define RAG_ERR_OOM 4           /* device or pinned-host allocation failed */
+#define RAG_ERR_UNSUPPORTED 5   /* shape outside what the kernels cover (d, k limits) */
+#define RAG_ERR_STATE 6         /* call not valid in the handle's current state */
+
+/* metrics: same meaning as faiss.METRIC_INNER_PRODUCT / faiss.METRIC_L2 (IndexFlatIP / IndexFlatL2) */
+#define RAG_METRIC_INNER_PRODUCT 0
+#define RAG_METRIC_L2 1
+
+/* ---- library ------------------------------------------------------------------------- */
+
+/* ABI version of the loaded library (compare with RAG_AMD_ABI_VERSION). Never fails. */
+int rag_abi_version(void);
+
+/* Number of visible HIP devices (0 when there is no GPU / no driver). Never fails. */
+int rag_device_count(void);
+
+/* Thread-local, NUL-terminated description of the last failure on this thread. */
+const char* rag_last_error(void);
+
+/* ---- flat index: exhaustive fp32 scan + exact top-k ----------------------------------- */
+
+typedef struct rag_index rag_index;
+
+/* Create an empty flat index of dimension d on `device`.
+ * Replaces: faiss.read_index() producing an IndexFlatIP / IndexFlatL2 (faiss_store.py:66-69). */
+int rag_index_create(int32_t d, int32_t metric, int32_t device, rag_index** out);
+
+/* Release the index and its device memory.  Replaces FAISSStore.unload (faiss_store.py:160-171). */
+int rag_index_destroy(rag_index* h);
+
+/* Make room for at least n_total rows (optional; add grows geometrically otherwise). */
+int rag_index_reserve(rag_index* h, int64_t n_total);
+
+/* Append n rows (row-major, d floats each) from host memory; ids are insertion row numbers,
+ * as IndexFlat assigns them (scripts/create_test_docs.py:92-97 relies on that). */
+int rag_index_add(rag_index* h, const float* rows_host, int64_t n);
+
+/* Same, rows already in device memory on the handle's device (device-to-device copy on `stream`). */
+int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t n, void* stream);
+
+/* Append n deterministic synthetic unit-norm rows generated on the device (bench/test corpus;
+ * the generator is restated bit-exactly by oracle/flat_oracle.c:rago_synth_rows). Row r of the
+ * whole index is a pure function of (seed, global row number r + row_number_offset). */
+int rag_index_add_synthetic(rag_index* h, int64_t n, uint64_t seed, int64_t row_number_offset);
+
+/* Number of rows / dimension / metric.  Replaces index.ntotal (faiss_store.py:178-183). */
+int64_t rag_index_ntotal(const rag_index* h);
+int32_t rag_index_dim(const rag_index* h);
+int32_t rag_index_metric(const rag_index* h);
+
+/* Value added to every returned id (shard base row when the corpus is split over GPUs). */
+int rag_index_set_id_offset(rag_index* h, int64_t id_offset);
+
+/* Exact search.  Replaces index.search(embeddings, k) (faiss_store.py:152).
+ *   queries_host : nq x d fp32, row-major (caller-owned)
+ *   out_scores   : nq x k fp32 — inner products sorted descending (IP) or squared L2
+ *                  distances sorted ascending (L2)
+ *   out_ids      : nq x k int64 — row ids; slots beyond ntotal hold -1 with score
+ *                  -FLT_MAX (IP) / +FLT_MAX (L2), as IndexFlat pads them
+ * Ties are broken by ascending id.  Blocks until the results are in the output buffers. */
+int rag_index_search(rag_index* h, const float* queries_host, int32_t nq, int32_t k,
+                     float* out_scores, int64_t* out_ids);
+
+/* Same with queries and outputs in device memory; asynchronous on `stream`. */
+int rag_index_search_device(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                            float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+
+/* Copy rows [row0, row0+n) back to host memory (parity spot checks at full size). */
+int rag_index_get_rows(rag_index* h, int64_t row0, int64_t n, float* out_rows_host);
+
+/* Scan-kernel profiling: when enabled every search brackets its scan kernel with HIP events
+ * on the launch stream.  rag_index_profile returns the accumulated kernel time and launch
+ * count since the last reset (it synchronises the recorded events). */
+int rag_index_profile_enable(rag_index* h, int32_t on);
+int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* scan_launches, int32_t reset);
+
+/* Largest k the fused scan+select kernel supports for (d, nq) on this build; 0 if d unsupported. */
+int32_t rag_index_max_k(int32_t d, int32_t nq);
+
+/* Merge per-shard top-k lists (the step after the RCCL all-gather):
+ *   scores_dev / ids_dev : n_shards x nq x k, each list sorted as rag_index_search returns it
+ *   out                  : nq x k, same ordering rule (score, then ascending id)
+ * metric picks the direction.  Asynchronous on `stream`. */
+int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                          const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
+                          int64_t* out_ids_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAG_AMD_H */

@@ -1,0 +1,523 @@
+// flat_kernels.hip.h — gfx950 kernels of the flat (exhaustive) index.
+//
+// Replaces the arithmetic behind faiss IndexFlat{IP,L2}.search as called from the reference at
+// src/pipeline/components/faiss_store.py:152.  Semantics (summation order, tie rule, padding)
+// are those of oracle/flat_oracle.c, which the tests hold this file to bit-for-bit.
+//
+// K1  scan_topk_kernel   one pass over the corpus: 32-row x 32-query score tiles on the exact
+//                        fp32 MFMA (v_mfma_f32_32x32x2_f32 == fmaf chain), threshold filter in
+//                        registers, candidates appended to per-workgroup LDS buffers, buffers
+//                        compacted by a wave-level bitonic sort when one overflows.
+// K2  merge_keys_kernel  per query: top-k of the per-workgroup lists (LDS bitonic sort), final
+//                        pass decodes keys into (score, id).
+// plus small helpers (row norms, query norms, synthetic corpus, neutral fill).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ragk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int kQT = 32;        // queries per scan pass (MFMA N)
+constexpr int kTileRows = 32;  // corpus rows per wave tile (MFMA M)
+constexpr int kScanWaves = 8;  // waves per scan workgroup (2 per SIMD)
+constexpr int kMergeThreads = 256;
+constexpr int kMergeMaxKeys = 4096;  // keys sorted per merge workgroup (32 KiB LDS)
+
+// ---- ranking keys -------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t ord32(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// larger key = better: higher score first, then smaller row.  0 = empty slot.
+__device__ __forceinline__ u64 make_key(float score, uint32_t row) {
+    return ((u64)ord32(score) << 32) | (u64)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// Wave-level bitonic sort, descending over index i = e*64 + lane, E keys per lane.
+template <int E>
+__device__ __forceinline__ void wave_sort_desc(u64 (&key)[E], int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64 * E; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride >= 64) {
+                const int se = stride >> 6;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & se) == 0) {
+                        const bool up = (((e * 64) & size) == 0);  // size >= 128 here: lane-independent
+                        u64 a = key[e], b = key[e | se];
+                        u64 hi = umax64(a, b), lo = umin64(a, b);
+                        key[e] = up ? hi : lo;
+                        key[e | se] = up ? lo : hi;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = e * 64 + lane;
+                    const bool up = ((i & size) == 0);
+                    const bool lower = ((lane & stride) == 0);
+                    u64 other = shfl_xor_u64(key[e], stride);
+                    key[e] = (lower == up) ? umax64(key[e], other) : umin64(key[e], other);
+                }
+            }
+        }
+    }
+}
+
+// ---- K1: scan + select ----------------------------------------------------------------------
+
+struct ScanParams {
+    const float* X;        // corpus, row-major, row_stride floats per row (zero padded to d8)
+    const float* xnorm;    // canonical squared norms (L2 metric only)
+    const float* Q;        // queries, row-major nq x d (un-padded)
+    u64* partial;          // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
+    long long n_rows;
+    long long row_stride;
+    int d;                 // logical dimension
+    int d8;                // d rounded up to a multiple of 8
+    int nq;                // 1..32
+    int k;
+    int n_tiles;           // ceil(n_rows / 32)
+    int n_iters;           // tiles per wave
+};
+
+// LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32]
+__host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16;
+}
+
+// E = buffer capacity / 64, D = register ring depth (steps of 8 columns in flight), L2 = metric.
+template <int E, int D, bool L2>
+__global__ __launch_bounds__(kScanWaves * 64) void scan_topk_kernel(const ScanParams p) {
+    constexpr int C = 64 * E;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int S = p.d8 >> 3;
+
+    f32x4* qf = reinterpret_cast<f32x4*>(smem);
+    u64* keys = reinterpret_cast<u64*>(smem + (size_t)S * 1024);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(keys + (size_t)kQT * C);
+    float* thr = reinterpret_cast<float*>(cnt + kQT);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
+
+    // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
+    for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
+        const int s = idx >> 6, l = idx & 63;
+        const int qrow = l & 31, col = 8 * s + 4 * (l >> 5);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qrow < p.nq) {
+            const float* src = p.Q + (size_t)qrow * p.d + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < p.d) v[j] = src[j];
+        }
+        qf[idx] = v;
+    }
+    if (tid < kQT) {
+        cnt[tid] = 0;
+        thr[tid] = -__builtin_inff();
+    }
+    if (tid < 4) flag[tid] = 0;
+    __syncthreads();
+
+    const long long last_row = p.n_rows - 1;
+    const int tiles_per_iter = gridDim.x * kScanWaves;
+    int tile = blockIdx.x * kScanWaves + wave;
+    auto row_ptr = [&](int t) -> const float* {
+        long long row = (long long)t * kTileRows + r;
+        row = row < last_row ? row : last_row;
+        return p.X + row * p.row_stride + 4 * h;
+    };
+
+    f32x4 xb[D];
+    const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
+#pragma unroll
+    for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+
+    // Overflow flags: pass number seq (one pass = one trip through the barrier loop below) owns
+    // flag[seq & 3]; appends raise the flag of the pass that will check them, and pass seq clears
+    // the slot of pass seq + 2, so a wave that has already left a pass never races a wave that is
+    // still reading that pass's flag.
+    uint32_t seq = 0;
+    for (int it = 0; it < p.n_iters; ++it, tile += tiles_per_iter) {
+        const bool active = tile < p.n_tiles;  // wave-uniform
+        const int tnext = tile + tiles_per_iter;
+        const float* pn = row_ptr(tnext < p.n_tiles ? tnext : p.n_tiles - 1);
+
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+        // One step = 8 columns: 4 MFMAs on ring slot i, then the slot is refilled D steps ahead and
+        // the next step's query fragment is fetched from LDS.  sched_barrier pins that order: left
+        // alone hipcc sinks all D refills to the end of the unrolled body, where the first one is
+        // waited for immediately.
+        f32x4 qcur = qf[lane];
+        int s0 = 0;
+        for (; s0 < S - D; s0 += D) {
+            const float* src = pc + 8 * (s0 + D);
+            const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const f32x4 qn = qs[i * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][0], qcur[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][1], qcur[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][2], qcur[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][3], qcur[3], acc, 0, 0, 0);
+                xb[i] = *reinterpret_cast<const f32x4*>(src + 8 * i);
+                qcur = qn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ring refill (VMEM read)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // last D steps: refill the ring from the next tile
+        {
+            const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                // the fragment after the last step is never used; stay inside the Q image
+                const f32x4 qn = qs[(i + 1 < D ? i : -1 - s0) * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][0], qcur[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][1], qcur[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][2], qcur[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][3], qcur[3], acc, 0, 0, 0);
+                xb[i] = *reinterpret_cast<const f32x4*>(pn + 8 * i);
+                qcur = qn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ring refill (VMEM read)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        pc = pn;
+
+        // ---- ranking scores.  Lane (r, h): query r, tile rows (i&3) + 8(i>>2) + 4h.
+        const long long row0 = (long long)tile * kTileRows;
+        float sc[16];
+        if (L2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+                const long long rb = row0 + 8 * g + 4 * h;
+                if (active) {
+                    if (rb + 3 <= last_row) {
+                        xn = *reinterpret_cast<const f32x4*>(p.xnorm + rb);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (rb + j <= last_row) xn[j] = p.xnorm[rb + j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[4 * g + j] = __builtin_fmaf(2.0f, acc[4 * g + j], -xn[j]) + 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = acc[i] + 0.0f;
+        }
+
+        // ---- filter + append
+        uint32_t pending = 0;
+        if (active) {
+            float t = thr[r];
+            float m = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, sc[i]);
+            if (m >= t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (sc[i] >= t && row <= last_row) {
+                        const uint32_t slot = atomicAdd(&cnt[r], 1u);
+                        if (slot < (uint32_t)C) {
+                            keys[(size_t)r * C + slot] = make_key(sc[i], (uint32_t)row);
+                        } else {
+                            pending |= 1u << i;
+                            flag[seq & 3] = 1;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- overflow handling: synchronised compaction of every query, then retry
+        for (;;) {
+            __syncthreads();
+            const bool need = flag[seq & 3] != 0;  // workgroup-uniform
+            if (tid == 0) flag[(seq + 2) & 3] = 0;
+            ++seq;
+            if (!need) break;
+            for (int q = wave; q < kQT; q += kScanWaves) {
+                const uint32_t n = min(cnt[q], (uint32_t)C);
+                if (n > (uint32_t)p.k || cnt[q] > (uint32_t)C) {
+                    u64 kk[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t idx = e * 64 + lane;
+                        kk[e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+                    }
+                    wave_sort_desc<E>(kk, lane);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int idx = e * 64 + lane;
+                        if (idx < p.k) keys[(size_t)q * C + idx] = kk[e];
+                        if (idx == p.k - 1) thr[q] = n >= (uint32_t)p.k ? unord32((uint32_t)(kk[e] >> 32)) : -__builtin_inff();
+                    }
+                    if (lane == 0) cnt[q] = min(n, (uint32_t)p.k);
+                }
+            }
+            __syncthreads();
+            if (pending) {
+                const float t = thr[r];
+                uint32_t still = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if ((pending >> i) & 1u) {
+                        if (sc[i] >= t) {
+                            const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            const uint32_t slot = atomicAdd(&cnt[r], 1u);
+                            if (slot < (uint32_t)C) {
+                                keys[(size_t)r * C + slot] = make_key(sc[i], (uint32_t)row);
+                            } else {
+                                still |= 1u << i;
+                                flag[seq & 3] = 1;
+                            }
+                        }
+                    }
+                }
+                pending = still;
+            }
+        }
+    }
+
+    // ---- epilogue: sort every buffer, emit k keys per query for this workgroup
+    for (int q = wave; q < kQT; q += kScanWaves) {
+        const uint32_t n = min(cnt[q], (uint32_t)C);
+        u64 kk[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const uint32_t idx = e * 64 + lane;
+            kk[e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+        }
+        wave_sort_desc<E>(kk, lane);
+        u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * p.k;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int idx = e * 64 + lane;
+            if (idx < p.k) out[idx] = kk[e];
+        }
+    }
+}
+
+// ---- K2: merge ------------------------------------------------------------------------------
+
+struct MergeParams {
+    const u64* in;      // [nq][m_in] keys (0 = empty)
+    u64* out;           // [nq][n_chunks][k] keys (intermediate pass)
+    float* out_scores;  // [nq][k] (final pass)
+    long long* out_ids; // [nq][k] (final pass)
+    const float* qnorm; // [nq] canonical ||q||^2 (L2, final pass)
+    long long id_offset;
+    int m_in;           // keys per query on input
+    int chunk;          // keys per workgroup (<= kMergeMaxKeys)
+    int p2;             // power of two >= chunk
+    int k;
+    int final_pass;     // decode keys into scores / ids
+    int metric;         // 0 IP, 1 L2
+    int out_stride;     // row stride of out_scores / out_ids (elements)
+};
+
+__global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(const MergeParams p) {
+    __shared__ u64 sk[kMergeMaxKeys];
+    const int q = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const u64* src = p.in + (size_t)q * p.m_in + (size_t)c * p.chunk;
+    const int n = min(p.chunk, p.m_in - c * p.chunk);
+    for (int i = tid; i < p.p2; i += kMergeThreads) sk[i] = i < n ? src[i] : 0ull;
+    __syncthreads();
+    for (int size = 2; size <= p.p2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (p.p2 >> 1); t += kMergeThreads) {
+                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+                const int j = i | stride;
+                const bool up = ((i & size) == 0);
+                const u64 a = sk[i], b = sk[j];
+                const bool swap = up ? (a < b) : (a > b);
+                if (swap) {
+                    sk[i] = b;
+                    sk[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (!p.final_pass) {
+        u64* dst = p.out + ((size_t)q * gridDim.x + c) * p.k;
+        for (int i = tid; i < p.k; i += kMergeThreads) dst[i] = i < p.p2 ? sk[i] : 0ull;
+    } else {
+        for (int i = tid; i < p.k; i += kMergeThreads) {
+            const u64 key = i < p.p2 ? sk[i] : 0ull;
+            float s;
+            long long id;
+            if (key == 0ull) {
+                s = p.metric ? 3.402823466e+38f : -3.402823466e+38f;
+                id = -1;
+            } else {
+                const float rs = unord32((uint32_t)(key >> 32));
+                if (p.metric) {
+                    const float dist = p.qnorm[q] - rs;
+                    s = dist < 0.f ? 0.f : dist;
+                } else {
+                    s = rs;
+                }
+                id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + p.id_offset;
+            }
+            p.out_scores[(size_t)q * p.out_stride + i] = s;
+            p.out_ids[(size_t)q * p.out_stride + i] = id;
+        }
+    }
+}
+
+// Encode sorted (score, id) shard lists into keys for merge_keys_kernel (multi-GPU merge).
+// Ids must be < 2^32 after subtracting id_base (callers pass the smallest id as id_base).
+__global__ void encode_lists_kernel(const float* scores, const long long* ids, u64* keys, int n_shards,
+                                    int nq, int k, int metric, long long id_base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = n_shards * nq * k;
+    if (i >= total) return;
+    const int j = i % k, q = (i / k) % nq, g = i / (k * nq);
+    const long long id = ids[i];
+    u64 key = 0ull;
+    if (id >= 0) {
+        const float s = scores[i];
+        // L2 lists carry distances (ascending): rank by the negated distance
+        key = make_key(metric ? -s : s, (uint32_t)(id - id_base));
+    }
+    keys[((size_t)q * n_shards + g) * k + j] = key;
+}
+
+// Final pass for the multi-GPU merge: keys (as encoded above) -> (score, id).
+__global__ void decode_lists_kernel(const u64* keys, float* out_scores, long long* out_ids, int total,
+                                    int metric, long long id_base) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const u64 key = keys[i];
+    if (key == 0ull) {
+        out_scores[i] = metric ? 3.402823466e+38f : -3.402823466e+38f;
+        out_ids[i] = -1;
+    } else {
+        const float rs = unord32((uint32_t)(key >> 32));
+        out_scores[i] = metric ? -rs : rs;
+        out_ids[i] = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + id_base;
+    }
+}
+
+// ---- helpers ----------------------------------------------------------------------------------
+
+// Canonical fp32 dot (oracle/flat_oracle.c:rago_dot): zero-padded to a multiple of 8, each group
+// of 8 visited 0,4,1,5,2,6,3,7, one fmaf per term.
+__device__ __forceinline__ float canonical_sqnorm(const float* x, int d) {
+    float acc = 0.f;
+    const int d8 = (d + 7) & ~7;
+    for (int s = 0; s < d8; s += 8) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k0 = s + t, k1 = s + 4 + t;
+            const float a = k0 < d ? x[k0] : 0.f;
+            const float b = k1 < d ? x[k1] : 0.f;
+            acc = __builtin_fmaf(a, a, acc);
+            acc = __builtin_fmaf(b, b, acc);
+        }
+    }
+    return acc;
+}
+
+__global__ void row_sqnorm_kernel(const float* X, long long row_stride, int d, long long row0, long long n,
+                                  float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[row0 + i] = canonical_sqnorm(X + (row0 + i) * row_stride, d);
+}
+
+__global__ void fill_neutral_kernel(float* scores, long long* ids, int total, int metric) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    scores[i] = metric ? 3.402823466e+38f : -3.402823466e+38f;
+    ids[i] = -1;
+}
+
+// Synthetic corpus, bit-exact with oracle/flat_oracle.c:rago_synth_rows.
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float synth_elem(u64 seed, u64 row, uint32_t col, uint32_t d) {
+    const u64 rr = mix64(seed ^ mix64(row * (u64)d + col));
+    const int s = (int)(rr & 0xFFFF) + (int)((rr >> 16) & 0xFFFF) + (int)((rr >> 32) & 0xFFFF) +
+                  (int)((rr >> 48) & 0xFFFF);
+    return (float)(s - 131070) * (1.0f / 65536.0f);
+}
+// 1/sqrt from multiplies and fmas only, bit-exact with oracle/flat_oracle.c:rago_rsqrt
+__device__ __forceinline__ float synth_rsqrt(float v) {
+    if (!(v > 0.f)) return 0.f;
+    float y = __uint_as_float(0x5f3759dfu - (__float_as_uint(v) >> 1));
+    const float hh = __fmul_rn(0.5f, v);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float t = __fmul_rn(y, y);
+        const float w = __builtin_fmaf(-hh, t, 1.5f);
+        y = __fmul_rn(y, w);
+    }
+    return y;
+}
+// pass 1: inv[i] = rsqrt(sum_j elem^2), the sum a sequential fmaf chain in index order
+__global__ void synth_inv_kernel(u64 seed, long long row_number0, long long n, int d, float* inv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ss = 0.f;
+    for (int j = 0; j < d; ++j) {
+        const float v = synth_elem(seed, (u64)(row_number0 + i), (uint32_t)j, (uint32_t)d);
+        ss = __builtin_fmaf(v, v, ss);
+    }
+    inv[i] = synth_rsqrt(ss);
+}
+// pass 2: coalesced element fill, X[(dst_row0+i)*stride + j] = elem * inv[i] (pad columns = 0)
+__global__ void synth_fill_kernel(u64 seed, long long row_number0, long long n, int d, int d8,
+                                  long long row_stride, const float* inv, float* X, long long dst_row0) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = n * (long long)d8;
+    if (idx >= total) return;
+    const long long i = idx / d8;
+    const int j = (int)(idx - i * d8);
+    float v = 0.f;
+    if (j < d) v = __fmul_rn(synth_elem(seed, (u64)(row_number0 + i), (uint32_t)j, (uint32_t)d), inv[i]);
+    X[(dst_row0 + i) * row_stride + j] = v;
+}
+
+}  // namespace ragk

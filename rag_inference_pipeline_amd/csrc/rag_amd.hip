@@ -1,0 +1,657 @@
+// rag_amd.hip — C ABI (include/rag_amd.h) over the gfx950 kernels in flat_kernels.hip.h.
+// Host side of the flat index: device memory, streams, launch geometry, status codes.
+// There is no CPU compute path in this file: without a HIP device every entry point fails.
+#include "../../include/rag_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "flat_kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                                \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return RAG_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return RAG_OK;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// Candidate-buffer capacity (64 * E) for a (d8, k) pair; 0 when nothing fits the 160 KiB LDS.
+int pick_capacity(int d8, int k) {
+    constexpr size_t kLdsMax = 160 * 1024;
+    const int want = k <= 32 ? 64 : (k <= 96 ? 128 : 256);
+    for (int c = want; c <= 256; c <<= 1)
+        if (c >= k + 16 && ragk::scan_lds_bytes(d8, c) <= kLdsMax) return c;
+    for (int c = want >> 1; c >= 64; c >>= 1)
+        if (c >= k + 16 && ragk::scan_lds_bytes(d8, c) <= kLdsMax) return c;
+    return 0;
+}
+
+int pick_ring(int S) {
+    for (int dpt : {8, 4, 2})
+        if (S % dpt == 0 && S >= dpt) return dpt;
+    return 1;
+}
+
+using ScanFn = void (*)(const ragk::ScanParams);
+
+template <int E, int D>
+ScanFn scan_fn_metric(bool l2) {
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<E, D, true> : (ScanFn)ragk::scan_topk_kernel<E, D, false>;
+}
+template <int E>
+ScanFn scan_fn_ring(int ring, bool l2) {
+    switch (ring) {
+        case 8: return scan_fn_metric<E, 8>(l2);
+        case 4: return scan_fn_metric<E, 4>(l2);
+        case 2: return scan_fn_metric<E, 2>(l2);
+        default: return scan_fn_metric<E, 1>(l2);
+    }
+}
+ScanFn scan_fn(int cap, int ring, bool l2) {
+    switch (cap) {
+        case 64: return scan_fn_ring<1>(ring, l2);
+        case 128: return scan_fn_ring<2>(ring, l2);
+        default: return scan_fn_ring<4>(ring, l2);
+    }
+}
+
+}  // namespace
+
+struct rag_index {
+    int device = 0;
+    int d = 0, d8 = 0, metric = 0;
+    int n_cus = 0;
+    long long n = 0, cap_rows = 0;
+    long long id_offset = 0;
+    float* X = nullptr;        // cap_rows x d8
+    float* xnorm = nullptr;    // cap_rows (L2 only; padded to a multiple of 4 rows)
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+
+    // per-search workspace (grown on demand, device memory)
+    float* q_dev = nullptr;  size_t q_dev_cap = 0;          // queries staged from the host
+    float* qnorm = nullptr;                                  // kQT floats
+    ragk::u64* partial = nullptr; size_t partial_cap = 0;   // kQT * grid * k keys
+    ragk::u64* merge_a = nullptr; ragk::u64* merge_b = nullptr; size_t merge_cap = 0;
+    float* out_s_dev = nullptr; long long* out_i_dev = nullptr; size_t out_cap = 0;
+    // pinned host staging
+    float* q_pin = nullptr; size_t q_pin_cap = 0;
+    float* out_s_pin = nullptr; long long* out_i_pin = nullptr; size_t out_pin_cap = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    double prof_ms = 0.0;
+    long long prof_launches = 0;
+};
+
+namespace {
+
+int grow_rows(rag_index* h, long long want) {
+    if (want <= h->cap_rows) return RAG_OK;
+    long long cap = std::max<long long>(want, h->cap_rows + h->cap_rows / 2);
+    cap = (cap + 31) / 32 * 32;
+    float* nx = nullptr;
+    int rc = dev_alloc(&nx, (size_t)cap * h->d8);
+    if (rc) return rc;
+    float* nn = nullptr;
+    if (h->metric == RAG_METRIC_L2) {
+        rc = dev_alloc(&nn, (size_t)cap);
+        if (rc) {
+            (void)hipFree(nx);
+            return rc;
+        }
+    }
+    if (h->n > 0) {
+        HIP_TRY(hipMemcpyAsync(nx, h->X, (size_t)h->n * h->d8 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        if (nn) HIP_TRY(hipMemcpyAsync(nn, h->xnorm, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->X) (void)hipFree(h->X);
+    if (h->xnorm) (void)hipFree(h->xnorm);
+    h->X = nx;
+    h->xnorm = nn;
+    h->cap_rows = cap;
+    return RAG_OK;
+}
+
+int after_add(rag_index* h, long long row0, long long n, hipStream_t st) {
+    if (h->metric == RAG_METRIC_L2 && n > 0) {
+        const int bs = 256;
+        ragk::row_sqnorm_kernel<<<dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, st>>>(h->X, h->d8, h->d, row0, n,
+                                                                                         h->xnorm);
+        HIP_TRY(hipGetLastError());
+    }
+    return RAG_OK;
+}
+
+int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
+    const size_t part = (size_t)ragk::kQT * grid * k;
+    if (part > h->partial_cap) {
+        if (h->partial) (void)hipFree(h->partial);
+        h->partial = nullptr;
+        h->partial_cap = 0;
+        int rc = dev_alloc(&h->partial, part);
+        if (rc) return rc;
+        h->partial_cap = part;
+    }
+    // merge ping-pong: after the first pass at most ceil(grid*k / chunk) * k keys per query
+    const size_t mer = (size_t)ragk::kQT * (((size_t)grid * k + ragk::kMergeMaxKeys - 1) / ragk::kMergeMaxKeys + 2) * 2 * k;
+    if (mer > h->merge_cap) {
+        if (h->merge_a) (void)hipFree(h->merge_a);
+        if (h->merge_b) (void)hipFree(h->merge_b);
+        h->merge_a = h->merge_b = nullptr;
+        h->merge_cap = 0;
+        int rc = dev_alloc(&h->merge_a, mer);
+        if (rc) return rc;
+        rc = dev_alloc(&h->merge_b, mer);
+        if (rc) return rc;
+        h->merge_cap = mer;
+    }
+    if (!h->qnorm) {
+        int rc = dev_alloc(&h->qnorm, (size_t)ragk::kQT);
+        if (rc) return rc;
+    }
+    (void)nq_total;
+    return RAG_OK;
+}
+
+// One pass of <= 32 queries: scan + merge into out (device pointers, row stride k).
+int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i, hipStream_t st) {
+    using namespace ragk;
+    const int cap = pick_capacity(h->d8, k);
+    if (cap == 0)
+        return fail(RAG_ERR_UNSUPPORTED, "k=%d with d=%d exceeds the fused scan kernel's LDS budget (max k %d)", k, h->d,
+                    rag_index_max_k(h->d, nq));
+    const int S = h->d8 / 8;
+    const int ring = pick_ring(S);
+    const bool l2 = h->metric == RAG_METRIC_L2;
+    const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
+    const int n_tiles = (int)n_tiles_ll;
+    int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + kScanWaves - 1) / kScanWaves);
+    grid = std::max(grid, 1);
+    const int n_iters = (n_tiles + grid * kScanWaves - 1) / (grid * kScanWaves);
+
+    int rc = ensure_search_ws(h, nq, k, grid);
+    if (rc) return rc;
+
+    if (l2) {
+        row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(q_dev, h->d, h->d, 0, nq, h->qnorm);
+        HIP_TRY(hipGetLastError());
+    }
+
+    ScanParams sp;
+    sp.X = h->X;
+    sp.xnorm = h->xnorm;
+    sp.Q = q_dev;
+    sp.partial = h->partial;
+    sp.n_rows = h->n;
+    sp.row_stride = h->d8;
+    sp.d = h->d;
+    sp.d8 = h->d8;
+    sp.nq = nq;
+    sp.k = k;
+    sp.n_tiles = n_tiles;
+    sp.n_iters = n_iters;
+    ScanFn fn = scan_fn(cap, ring, l2);
+    const size_t lds = scan_lds_bytes(h->d8, cap);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kScanWaves * 64), lds, st, sp);
+    HIP_TRY(hipGetLastError());
+    if (h->prof) {
+        HIP_TRY(hipEventRecord(e1, st));
+        h->prof_events.emplace_back(e0, e1);
+    }
+
+    // merge passes: [q][m] keys -> [q][k]
+    const u64* in = h->partial;
+    int m = grid * k;
+    u64* bufs[2] = {h->merge_a, h->merge_b};
+    int which = 0;
+    for (;;) {
+        const int chunk = std::min(m, kMergeMaxKeys / k * k);  // whole lists per chunk
+        const int n_chunks = (m + chunk - 1) / chunk;
+        MergeParams mp;
+        mp.in = in;
+        mp.out = bufs[which];
+        mp.out_scores = out_s;
+        mp.out_ids = out_i;
+        mp.qnorm = h->qnorm;
+        mp.id_offset = h->id_offset;
+        mp.m_in = m;
+        mp.chunk = chunk;
+        mp.p2 = next_pow2(chunk);
+        mp.k = k;
+        mp.final_pass = n_chunks == 1;
+        mp.metric = h->metric;
+        mp.out_stride = k;
+        merge_keys_kernel<<<dim3(n_chunks, nq), dim3(kMergeThreads), 0, st>>>(mp);
+        HIP_TRY(hipGetLastError());
+        if (n_chunks == 1) break;
+        in = bufs[which];
+        m = n_chunks * k;
+        which ^= 1;
+    }
+    return RAG_OK;
+}
+
+int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i,
+                         hipStream_t st) {
+    if (h->n == 0) {
+        const int total = nq * k;
+        ragk::fill_neutral_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(out_s, out_i, total, h->metric);
+        HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
+    for (int q0 = 0; q0 < nq; q0 += ragk::kQT) {
+        const int nb = std::min(ragk::kQT, nq - q0);
+        int rc = search_pass(h, q_dev + (size_t)q0 * h->d, nb, k, out_s + (size_t)q0 * k, out_i + (size_t)q0 * k, st);
+        if (rc) return rc;
+    }
+    return RAG_OK;
+}
+
+int check_search_args(const rag_index* h, const void* q, int nq, int k, const void* s, const void* i) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    if (nq < 0 || k <= 0) return fail(RAG_ERR_INVALID_ARG, "nq=%d k=%d out of range", nq, k);
+    if (nq > 0 && (!q || !s || !i)) return fail(RAG_ERR_INVALID_ARG, "null query or output buffer");
+    return RAG_OK;
+}
+
+}  // namespace
+
+// ---- library ------------------------------------------------------------------------------------
+
+extern "C" int rag_abi_version(void) { return RAG_AMD_ABI_VERSION; }
+
+extern "C" int rag_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* rag_last_error(void) { return g_err; }
+
+// ---- flat index ------------------------------------------------------------------------------------
+
+extern "C" int rag_index_create(int32_t d, int32_t metric, int32_t device, rag_index** out) {
+    if (!out) return fail(RAG_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (d <= 0 || d > 65536) return fail(RAG_ERR_INVALID_ARG, "dimension %d out of range", d);
+    if (metric != RAG_METRIC_INNER_PRODUCT && metric != RAG_METRIC_L2)
+        return fail(RAG_ERR_INVALID_ARG, "unknown metric %d", metric);
+    const int ndev = rag_device_count();
+    if (ndev <= 0) return fail(RAG_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RAG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    const int d8 = round_up(d, 8);
+    if (pick_capacity(d8, 1) == 0)
+        return fail(RAG_ERR_UNSUPPORTED, "dimension %d: query fragments (%d KiB) do not fit the 160 KiB LDS", d, d8 / 8);
+    DeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    rag_index* h = new (std::nothrow) rag_index();
+    if (!h) return fail(RAG_ERR_OOM, "host allocation failed");
+    h->device = device;
+    h->d = d;
+    h->d8 = d8;
+    h->metric = metric;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete h;
+        return fail(RAG_ERR_HIP, "hipGetDeviceProperties failed");
+    }
+    h->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return fail(RAG_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_destroy(rag_index* h) {
+    if (!h) return RAG_OK;
+    {
+        DeviceGuard g(h->device);
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        for (auto& ev : h->prof_events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->partial, h->merge_a, h->merge_b, h->out_s_dev, h->out_i_dev};
+        for (void* p : dptrs)
+            if (p) (void)hipFree(p);
+        void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
+        for (void* p : hptrs)
+            if (p) (void)hipHostFree(p);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_reserve(rag_index* h, int64_t n_total) {
+    if (!h || n_total < 0) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (n_total > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    return grow_rows(h, n_total);
+}
+
+extern "C" int rag_index_add(rag_index* h, const float* rows_host, int64_t n) {
+    if (!h || n < 0 || (n > 0 && !rows_host)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return RAG_OK;
+    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = grow_rows(h, h->n + n);
+    if (rc) return rc;
+    float* dst = h->X + (size_t)h->n * h->d8;
+    if (h->d8 != h->d) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * h->d8 * sizeof(float), h->stream));
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)h->d8 * sizeof(float), rows_host, (size_t)h->d * sizeof(float),
+                             (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice, h->stream));
+    rc = after_add(h, h->n, n, h->stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->n += n;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t n, void* stream) {
+    if (!h || n < 0 || (n > 0 && !rows_dev)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return RAG_OK;
+    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = grow_rows(h, h->n + n);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    float* dst = h->X + (size_t)h->n * h->d8;
+    if (h->d8 != h->d) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * h->d8 * sizeof(float), st));
+    HIP_TRY(hipMemcpy2DAsync(dst, (size_t)h->d8 * sizeof(float), rows_dev, (size_t)h->d * sizeof(float),
+                             (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyDeviceToDevice, st));
+    rc = after_add(h, h->n, n, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    h->n += n;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_add_synthetic(rag_index* h, int64_t n, uint64_t seed, int64_t row_number_offset) {
+    if (!h || n < 0) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (n == 0) return RAG_OK;
+    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    int rc = grow_rows(h, h->n + n);
+    if (rc) return rc;
+    const long long chunk = 1 << 20;  // rows per generator launch (bounds the inv scratch)
+    float* inv = nullptr;
+    rc = dev_alloc(&inv, (size_t)std::min<long long>(chunk, n));
+    if (rc) return rc;
+    for (long long done = 0; done < n; done += chunk) {
+        const long long m = std::min(chunk, n - done);
+        const long long rn0 = row_number_offset + h->n + done;
+        ragk::synth_inv_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream>>>(seed, rn0, m, h->d, inv);
+        const long long total = m * h->d8;
+        ragk::synth_fill_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream>>>(
+            seed, rn0, m, h->d, h->d8, h->d8, inv, h->X, h->n + done);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(inv);
+            return fail(RAG_ERR_HIP, "synthetic fill launch failed");
+        }
+    }
+    rc = after_add(h, h->n, n, h->stream);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    (void)hipFree(inv);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RAG_ERR_HIP, "synthetic fill: %s", hipGetErrorString(e));
+    h->n += n;
+    return RAG_OK;
+}
+
+extern "C" int64_t rag_index_ntotal(const rag_index* h) { return h ? h->n : 0; }
+extern "C" int32_t rag_index_dim(const rag_index* h) { return h ? h->d : 0; }
+extern "C" int32_t rag_index_metric(const rag_index* h) { return h ? h->metric : -1; }
+
+extern "C" int rag_index_set_id_offset(rag_index* h, int64_t id_offset) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->id_offset = id_offset;
+    return RAG_OK;
+}
+
+extern "C" int32_t rag_index_max_k(int32_t d, int32_t nq) {
+    (void)nq;
+    if (d <= 0) return 0;
+    const int d8 = round_up(d, 8);
+    int best = 0;
+    for (int c : {64, 128, 256})
+        if (ragk::scan_lds_bytes(d8, c) <= 160 * 1024) best = c - 16;
+    return best;
+}
+
+extern "C" int rag_index_search_device(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                                       float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
+    int rc = check_search_args(h, queries_dev, nq, k, out_scores_dev, out_ids_dev);
+    if (rc) return rc;
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return search_device_locked(h, queries_dev, nq, k, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), st);
+}
+
+extern "C" int rag_index_search(rag_index* h, const float* queries_host, int32_t nq, int32_t k, float* out_scores,
+                                int64_t* out_ids) {
+    int rc = check_search_args(h, queries_host, nq, k, out_scores, out_ids);
+    if (rc) return rc;
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    const size_t qn = (size_t)nq * h->d, on = (size_t)nq * k;
+    if (qn > h->q_dev_cap) {
+        if (h->q_dev) (void)hipFree(h->q_dev);
+        h->q_dev = nullptr;
+        h->q_dev_cap = 0;
+        rc = dev_alloc(&h->q_dev, qn);
+        if (rc) return rc;
+        h->q_dev_cap = qn;
+    }
+    if (qn > h->q_pin_cap) {
+        if (h->q_pin) (void)hipHostFree(h->q_pin);
+        h->q_pin = nullptr;
+        h->q_pin_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->q_pin), qn * sizeof(float), hipHostMallocDefault));
+        h->q_pin_cap = qn;
+    }
+    if (on > h->out_cap) {
+        if (h->out_s_dev) (void)hipFree(h->out_s_dev);
+        if (h->out_i_dev) (void)hipFree(h->out_i_dev);
+        h->out_s_dev = nullptr;
+        h->out_i_dev = nullptr;
+        h->out_cap = 0;
+        rc = dev_alloc(&h->out_s_dev, on);
+        if (rc) return rc;
+        rc = dev_alloc(&h->out_i_dev, on);
+        if (rc) return rc;
+        h->out_cap = on;
+    }
+    if (on > h->out_pin_cap) {
+        if (h->out_s_pin) (void)hipHostFree(h->out_s_pin);
+        if (h->out_i_pin) (void)hipHostFree(h->out_i_pin);
+        h->out_s_pin = nullptr;
+        h->out_i_pin = nullptr;
+        h->out_pin_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_s_pin), on * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_i_pin), on * sizeof(long long), hipHostMallocDefault));
+        h->out_pin_cap = on;
+    }
+    std::memcpy(h->q_pin, queries_host, qn * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->q_dev, h->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = search_device_locked(h, h->q_dev, nq, k, h->out_s_dev, h->out_i_dev, h->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->out_s_pin, h->out_s_dev, on * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->out_i_pin, h->out_i_dev, on * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(out_scores, h->out_s_pin, on * sizeof(float));
+    std::memcpy(out_ids, h->out_i_pin, on * sizeof(long long));
+    return RAG_OK;
+}
+
+extern "C" int rag_index_get_rows(rag_index* h, int64_t row0, int64_t n, float* out_rows_host) {
+    if (!h || row0 < 0 || n < 0 || (n > 0 && !out_rows_host)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (row0 + n > h->n) return fail(RAG_ERR_INVALID_ARG, "rows [%lld, %lld) beyond ntotal %lld", (long long)row0,
+                                     (long long)(row0 + n), h->n);
+    if (n == 0) return RAG_OK;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipMemcpy2DAsync(out_rows_host, (size_t)h->d * sizeof(float), h->X + (size_t)row0 * h->d8,
+                             (size_t)h->d8 * sizeof(float), (size_t)h->d * sizeof(float), (size_t)n,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RAG_OK;
+}
+
+extern "C" int rag_index_profile_enable(rag_index* h, int32_t on) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->prof = on != 0;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* scan_launches, int32_t reset) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (auto& ev : h->prof_events) {
+        HIP_TRY(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        h->prof_ms += ms;
+        h->prof_launches += 1;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    h->prof_events.clear();
+    if (scan_ms_total) *scan_ms_total = h->prof_ms;
+    if (scan_launches) *scan_launches = h->prof_launches;
+    if (reset) {
+        h->prof_ms = 0.0;
+        h->prof_launches = 0;
+    }
+    return RAG_OK;
+}
+
+// ---- shard merge ----------------------------------------------------------------------------------
+
+extern "C" int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                     const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
+                                     int64_t* out_ids_dev, void* stream) {
+    using namespace ragk;
+    if (n_shards <= 0 || nq < 0 || k <= 0 || !scores_dev || !ids_dev || !out_scores_dev || !out_ids_dev)
+        return fail(RAG_ERR_INVALID_ARG, "bad arguments");
+    if (metric != RAG_METRIC_INNER_PRODUCT && metric != RAG_METRIC_L2)
+        return fail(RAG_ERR_INVALID_ARG, "unknown metric %d", metric);
+    if (k > kMergeMaxKeys / 2) return fail(RAG_ERR_UNSUPPORTED, "k=%d too large for the merge kernel", k);
+    const int ndev = rag_device_count();
+    if (ndev <= 0) return fail(RAG_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(RAG_ERR_NO_DEVICE, "device %d out of range", device);
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    const int total_in = n_shards * nq * k;
+    int m = n_shards * k;
+    const size_t ws_keys = (size_t)nq * m * 2 + (size_t)nq * k;
+    u64* ws = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&ws), ws_keys * sizeof(u64), st));
+    u64* bufs[2] = {ws, ws + (size_t)nq * m};
+    u64* fin = ws + (size_t)nq * m * 2;
+    encode_lists_kernel<<<dim3((total_in + 255) / 256), dim3(256), 0, st>>>(scores_dev, reinterpret_cast<const long long*>(ids_dev),
+                                                                           bufs[0], n_shards, nq, k, metric, 0);
+    int which = 0;
+    for (;;) {
+        const int chunk = std::min(m, kMergeMaxKeys / k * k);
+        const int n_chunks = (m + chunk - 1) / chunk;
+        MergeParams mp;
+        mp.in = bufs[which];
+        mp.out = n_chunks == 1 ? fin : bufs[which ^ 1];
+        mp.out_scores = nullptr;
+        mp.out_ids = nullptr;
+        mp.qnorm = nullptr;
+        mp.id_offset = 0;
+        mp.m_in = m;
+        mp.chunk = chunk;
+        mp.p2 = next_pow2(chunk);
+        mp.k = k;
+        mp.final_pass = 0;
+        mp.metric = metric;
+        mp.out_stride = k;
+        merge_keys_kernel<<<dim3(n_chunks, nq), dim3(kMergeThreads), 0, st>>>(mp);
+        if (n_chunks == 1) break;
+        m = n_chunks * k;
+        which ^= 1;
+    }
+    const int total_out = nq * k;
+    decode_lists_kernel<<<dim3((total_out + 255) / 256), dim3(256), 0, st>>>(fin, out_scores_dev,
+                                                                            reinterpret_cast<long long*>(out_ids_dev), total_out, metric, 0);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(ws, st);
+    if (e != hipSuccess) return fail(RAG_ERR_HIP, "merge launch failed: %s", hipGetErrorString(e));
+    return RAG_OK;
+}

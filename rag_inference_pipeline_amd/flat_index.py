@@ -1,0 +1,122 @@
+"""FlatIndex — Python handle on the C-ABI flat index (rag_index_* in include/rag_amd.h).
+
+Plays the role of the `faiss.Index` object that the reference's FAISSStore holds
+(reference src/pipeline/components/faiss_store.py:37, :66-69, :152): `search(x, k) -> (D, I)`,
+`ntotal`, `d`.  All arithmetic happens in the HIP kernels; this file only marshals buffers.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import METRIC_INNER_PRODUCT, METRIC_L2  # noqa: F401  (re-exported)
+
+
+def _f32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class FlatIndex:
+    """Exhaustive fp32 index on one MI355X.  ids are insertion row numbers (+ id_offset)."""
+
+    def __init__(self, d: int, metric: int = METRIC_INNER_PRODUCT, device: int = 0) -> None:
+        self._lib = _native.lib()
+        self._h = C.c_void_p()
+        _native.check(self._lib.rag_index_create(int(d), int(metric), int(device), C.byref(self._h)))
+        self.d = int(d)
+        self.metric = int(metric)
+        self.device = int(device)
+
+    # -- lifecycle ------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rag_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:  # best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self) -> C.c_void_p:
+        if not self._h:
+            raise RuntimeError("FlatIndex is closed")
+        return self._h
+
+    # -- building -------------------------------------------------------------------------
+    def reserve(self, n_total: int) -> None:
+        _native.check(self._lib.rag_index_reserve(self._handle(), int(n_total)))
+
+    def add(self, rows: np.ndarray) -> None:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.d:
+            raise ValueError(f"rows must have shape (n, {self.d}), got {rows.shape}")
+        _native.check(self._lib.rag_index_add(self._handle(), _f32p(rows), rows.shape[0]))
+
+    def add_device(self, dev_ptr: int, n: int, stream: int = 0) -> None:
+        """Append n rows already resident on this device (e.g. a torch tensor's data_ptr())."""
+        _native.check(self._lib.rag_index_add_device(self._handle(), C.c_void_p(dev_ptr), int(n),
+                                                     C.c_void_p(stream)))
+
+    def add_synthetic(self, n: int, seed: int = 1234, row_number_offset: int = 0) -> None:
+        _native.check(self._lib.rag_index_add_synthetic(self._handle(), int(n), int(seed),
+                                                        int(row_number_offset)))
+
+    def set_id_offset(self, offset: int) -> None:
+        _native.check(self._lib.rag_index_set_id_offset(self._handle(), int(offset)))
+
+    @property
+    def ntotal(self) -> int:
+        return int(self._lib.rag_index_ntotal(self._handle()))
+
+    def get_rows(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.d), dtype=np.float32)
+        _native.check(self._lib.rag_index_get_rows(self._handle(), int(row0), int(n), _f32p(out)))
+        return out
+
+    # -- search ---------------------------------------------------------------------------
+    def search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """(D, I): D (nq, k) float32 best-first, I (nq, k) int64, -1 padded (faiss convention)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"queries must have shape (nq, {self.d}), got {q.shape}")
+        nq = q.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _native.check(self._lib.rag_index_search(self._handle(), _f32p(q), nq, int(k), _f32p(D),
+                                                 I.ctypes.data_as(C.POINTER(C.c_int64))))
+        return D, I
+
+    def search_device(self, q_ptr: int, nq: int, k: int, out_scores_ptr: int, out_ids_ptr: int,
+                      stream: int = 0) -> None:
+        """Asynchronous search on device buffers (pointers as ints, stream = hipStream_t)."""
+        _native.check(self._lib.rag_index_search_device(
+            self._handle(), C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(out_scores_ptr),
+            C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
+
+    # -- profiling ------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True) -> None:
+        _native.check(self._lib.rag_index_profile_enable(self._handle(), 1 if on else 0))
+
+    def profile(self, reset: bool = False) -> tuple[float, int]:
+        """(accumulated scan-kernel milliseconds from HIP events, number of scan launches)."""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        _native.check(self._lib.rag_index_profile(self._handle(), C.byref(ms), C.byref(n),
+                                                  1 if reset else 0))
+        return float(ms.value), int(n.value)
+
+    @staticmethod
+    def max_k(d: int, nq: int = 32) -> int:
+        return int(_native.lib().rag_index_max_k(int(d), int(nq)))
+
+
+def merge_topk_device(device: int, metric: int, n_shards: int, nq: int, k: int, scores_ptr: int,
+                      ids_ptr: int, out_scores_ptr: int, out_ids_ptr: int, stream: int = 0) -> None:
+    """Merge all-gathered per-shard lists on the device (rag_merge_topk_device)."""
+    _native.check(_native.lib().rag_merge_topk_device(
+        int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(scores_ptr),
+        C.c_void_p(ids_ptr), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
