@@ -1,0 +1,95 @@
+"""Settings consumed by the retrieval hot path.
+
+Mirrors the field names, defaults and environment behaviour of the reference's PipelineSettings
+(reference src/pipeline/config/__init__.py:54-59, fields :106-325) for the knobs this path reads.
+As in the reference, a field declared with an alias is set by its UPPER_CASE environment variable,
+a field without one only by its exact lower-case name ("Gotcha").
+pydantic-settings is not a dependency: the environment is read by hand.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Any
+
+from pydantic import BaseModel, ConfigDict, Field
+
+
+def _default_cpu_threads() -> int:
+    # reference config/__init__.py:32-46: min(16, cores) on a dedicated node
+    return min(16, os.cpu_count() or 8)
+
+
+class PipelineSettings(BaseModel):
+    model_config = ConfigDict(populate_by_name=True, extra="ignore")
+
+    # -- node / profile (reference :69-79, :247-257)
+    node_number: int = Field(default=1, alias="NODE_NUMBER")
+    profiling_run_id: str = Field(default="default", alias="PROFILING_RUN_ID")
+    pipeline_role_profile: str = Field(default="", alias="PIPELINE_ROLE_PROFILE")
+    role_profile_override_path: str = Field(default="", alias="ROLE_PROFILE_OVERRIDE_PATH")
+
+    # -- data (reference :106-116)
+    faiss_index_path: str = Field(default="faiss_index.bin", alias="FAISS_INDEX_PATH")
+    documents_dir: str = Field(default="documents/", alias="DOCUMENTS_DIR")
+
+    # -- device / threads (reference :118-141)
+    only_cpu: bool = Field(default=True, alias="ONLY_CPU")
+    faiss_threads: int = Field(default_factory=_default_cpu_threads, alias="FAISS_THREADS")
+    cpu_worker_threads: int = Field(default_factory=_default_cpu_threads, alias="CPU_WORKER_THREADS")
+
+    # -- batching / caches (reference :143-196)
+    enable_adaptive_batching: bool = Field(default=True, alias="ENABLE_ADAPTIVE_BATCHING")
+    cache_max_ttl: float = Field(default=60.0, alias="CACHE_MAX_TTL")
+    disable_cache_for_profiling: bool = Field(default=False, alias="DISABLE_CACHE_FOR_PROFILING")
+    retrieval_cache_capacity: int = Field(default=1000, alias="RETRIEVAL_CACHE_CAPACITY")
+    document_cache_capacity: int = Field(default=1000, alias="DOCUMENT_CACHE_CAPACITY")
+    faiss_use_mmap: bool = Field(default=False, alias="FAISS_USE_MMAP")
+    faiss_nprobe: int = Field(default=64, alias="FAISS_NPROBE")
+    documents_payload_mode: str = Field(default="id_only", alias="DOCUMENTS_PAYLOAD_MODE")
+
+    # -- un-aliased knobs (reference :226-325): settable by their lower-case name only
+    faiss_dim: int = 768
+    retrieval_k: int = 10
+    truncate_length: int = 512
+    rerank_top_n: int = 10
+    retrieval_batch_size: int = 32
+    retrieval_max_batch_delay_ms: int = 50
+    embedding_model_name: str = "BAAI/bge-base-en-v1.5"
+    reranker_model_name: str = "BAAI/bge-reranker-base"
+
+    # -- telemetry switches the executor looks at (reference :368-392)
+    enable_profiling: bool = Field(default=False, alias="ENABLE_PROFILING")
+    profiling_sample_rate: float = Field(default=1.0, alias="PROFILING_SAMPLE_RATE")
+    enable_torch_compile: bool = Field(default=False, alias="ENABLE_TORCH_COMPILE")
+
+    # -- knobs that exist only in this build
+    gpu_device: int = Field(default=0, alias="RAG_AMD_DEVICE")
+    faiss_metric: str = Field(default="ip", alias="RAG_AMD_METRIC")  # for files that carry no metric
+
+    @classmethod
+    def from_env(cls, env: dict[str, str] | None = None, **overrides: Any) -> "PipelineSettings":
+        env = dict(os.environ if env is None else env)
+        values: dict[str, Any] = {}
+        for name, field in cls.model_fields.items():
+            key = field.alias or name  # case-sensitive, like the reference
+            if key in env:
+                values[key] = env[key]
+        values.update(overrides)
+        return cls(**values)
+
+
+_settings: PipelineSettings | None = None
+
+
+def get_settings() -> PipelineSettings:
+    """Process-wide settings singleton (reference config/__init__.py:487-498)."""
+    global _settings
+    if _settings is None:
+        _settings = PipelineSettings.from_env()
+    return _settings
+
+
+def reset_settings() -> None:
+    global _settings
+    _settings = None

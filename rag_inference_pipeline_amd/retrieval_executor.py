@@ -1,0 +1,126 @@
+"""RetrievalExecutor — the batch function that drives the hot path.
+
+Counterpart of the reference's RetrievalExecutor (src/pipeline/services/retrieval/api.py:295-598):
+requests are grouped by a BatchScheduler; each batch runs, on a worker thread,
+
+    embeddings (precomputed or encode())  ->  index search  ->  document fetch  ->  optional rerank
+
+and yields one RetrievalResponseItem per request, in request order.  Semantics kept:
+  * the FIRST request decides between the precomputed-embedding path and encode(); a later request
+    without an embedding on the precomputed path is ValueError("Missing embedding in batch")
+    (api.py:69-84, :351-374)
+  * components are looked up by canonical alias in the registry; only the index is mandatory
+    (api.py:218-238, :361-363, :434, :537-542)
+  * without a document store, or in `id_only` mode, documents are id-only stubs (api.py:436-451)
+  * scores are zipped onto documents without a length check (api.py:491, strict=False)
+  * with a reranker the returned list and scores are the reranker's (api.py:495-514)
+What is different: rerank runs as ONE batched call over the whole batch (rerank_batch) instead of
+a thread pool of per-query calls (api.py:579-589) — the GPU cross-encoder batches all pairs.
+The `compressed` payload mode (lz4 of msgspec JSON, api.py:516-523) is wire format and not built.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import logging
+import time
+from collections.abc import Sequence
+from typing import Any
+
+import numpy as np
+
+from .batch_scheduler import Batch, BatchScheduler
+from .component_registry import ComponentRegistry
+from .components.document_store import Document as StoreDocument
+from .components.schemas import Document
+from .config import PipelineSettings, get_settings
+from .schemas import PendingRequest, RetrievalDocument, RetrievalRequestItem, RetrievalResponseItem
+from .telemetry import STAGE_DOCUMENT_FETCH, STAGE_EMBEDDING, STAGE_FAISS_SEARCH, stage_timers
+
+logger = logging.getLogger(__name__)
+
+
+def extract_embeddings_from_requests(requests: Sequence[Any]) -> np.ndarray:
+    rows = []
+    for req in requests:
+        if req.embedding is None:
+            raise ValueError("Missing embedding in batch")
+        rows.append(req.embedding)
+    return np.array(rows).astype("float32")
+
+
+class RetrievalExecutor:
+    def __init__(self, registry: ComponentRegistry, settings: PipelineSettings | None = None) -> None:
+        self.registry = registry
+        self.settings = settings or get_settings()
+        self.scheduler: BatchScheduler[RetrievalResponseItem] = BatchScheduler(
+            batch_size=self.settings.retrieval_batch_size,
+            max_batch_delay_ms=self.settings.retrieval_max_batch_delay_ms,
+            process_batch_fn=self._process_batch,
+            service_name="retrieval",
+            enable_adaptive=getattr(self.settings, "enable_adaptive_batching", True),
+        )
+
+    async def start(self) -> None:
+        await self.scheduler.start()
+
+    async def stop(self) -> None:
+        await self.scheduler.stop()
+
+    async def process_request(self, item: RetrievalRequestItem) -> RetrievalResponseItem:
+        req = PendingRequest(request_id=item.request_id, query=item.query, embedding=item.embedding,
+                             timestamp=time.time())
+        return await self.scheduler.enqueue(req)
+
+    async def _process_batch(self, batch: Batch[RetrievalResponseItem]) -> list[RetrievalResponseItem]:
+        # worker thread: the C ABI releases the GIL and the event loop keeps accepting requests
+        return await asyncio.get_running_loop().run_in_executor(None, self._process_batch_sync, batch)
+
+    # -- stages -------------------------------------------------------------------------------
+    def _get_embeddings(self, batch: Batch[RetrievalResponseItem]) -> np.ndarray:
+        if batch.requests[0].embedding is not None:
+            return extract_embeddings_from_requests(batch.requests)
+        embedder = self.registry.get("embedding_generator")
+        if not embedder:
+            raise RuntimeError("Embedding generator not available")
+        with stage_timers.track(STAGE_EMBEDDING):
+            return embedder.encode([req.query for req in batch.requests])
+
+    def _search(self, embeddings: np.ndarray) -> tuple[list[list[int]], list[list[float]]]:
+        index = self.registry.get("faiss_store")
+        with stage_timers.track(STAGE_FAISS_SEARCH):
+            distances, indices = index.search(embeddings, self.settings.retrieval_k)
+        return [row.tolist() for row in indices], [row.tolist() for row in distances]
+
+    def _fetch_documents(self, doc_ids_batch: list[list[int]]) -> list[list[StoreDocument]]:
+        store = self.registry.get("document_store")
+        mode = getattr(self.settings, "documents_payload_mode", "full")
+        if not store or mode == "id_only":
+            return [[StoreDocument(doc_id=i, title="", content="") for i in ids] for ids in doc_ids_batch]
+        with stage_timers.track(STAGE_DOCUMENT_FETCH):
+            return store.fetch_documents_batch(doc_ids_batch, truncate_length=self.settings.truncate_length)
+
+    @staticmethod
+    def _to_retrieval_docs(docs: list[StoreDocument], scores: list[float]) -> list[RetrievalDocument]:
+        return [RetrievalDocument(doc_id=d.doc_id, title=d.title, content=d.content,
+                                  category=d.category or "", score=float(s))
+                for d, s in zip(docs, scores)]  # no strict check, as the reference
+
+    def _process_batch_sync(self, batch: Batch[RetrievalResponseItem]) -> list[RetrievalResponseItem]:
+        if not self.registry.get("faiss_store"):
+            raise RuntimeError("FAISS store not available")
+        reranker = self.registry.get("reranker")
+        embeddings = self._get_embeddings(batch)
+        doc_ids_batch, distances_batch = self._search(embeddings)
+        documents_batch = self._fetch_documents(doc_ids_batch)
+        per_request = [self._to_retrieval_docs(docs, scores)
+                       for docs, scores in zip(documents_batch, distances_batch)]
+        if reranker:
+            inputs = [[Document(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category)
+                       for d in docs] for docs in per_request]
+            reranked = reranker.rerank_batch([req.query for req in batch.requests], inputs)
+            per_request = [[RetrievalDocument(doc_id=d.doc_id, title=d.title, content=d.content,
+                                              category=d.category, score=d.score) for d in docs]
+                           for docs in reranked]
+        return [RetrievalResponseItem(request_id=req.request_id, docs=docs, compressed_docs=None)
+                for req, docs in zip(batch.requests, per_request)]

@@ -118,3 +118,53 @@ def test_incremental_add_and_id_offset(gpu_required):
     Do, Io = oracle.search(X, Q, 10, id_offset=1_000_000)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
+
+
+def test_hip_reproduces_committed_golden(gpu_required):
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_search.json")) as fh:
+        cases = json.load(fh)
+    for name, c in cases.items():
+        X = oracle.synth_rows(c["corpus_seed"], 0, c["n"], c["d"])
+        Q = oracle.synth_rows(c["query_seed"], 0, c["nq"], c["d"])
+        D, I = _index(X, c["metric"]).search(Q, c["k"])
+        np.testing.assert_array_equal(I, np.array(c["ids"], dtype=np.int64), err_msg=name)
+        np.testing.assert_array_equal(D.view(np.uint32), np.array(c["scores_bits"], dtype=np.uint32), err_msg=name)
+
+
+def test_full_size_properties_10m_768(gpu_required):
+    """BASELINE size (10M x 768, batch 32, k 10): size-independent checks against the oracle.
+    (1) returned scores are bit-exact canonical dot products of the returned rows;
+    (2) lists are sorted (score desc, id asc) with distinct ids;
+    (3) no row of a 200k-row random sample beats the k-th result (completeness on a sample);
+    (4) planted queries (a corpus row itself) come back as their own top-1."""
+    from rag_inference_pipeline_amd.flat_index import FlatIndex
+    N, d, B, k, seed = 10_000_000, 768, 32, 10, 1234
+    idx = FlatIndex(d)
+    idx.add_synthetic(N, seed)
+    Q = oracle.synth_rows(4321, 0, B, d)
+    planted = [17, 5_000_001, 9_999_999]
+    for j, r in enumerate(planted):
+        Q[j] = oracle.synth_rows(seed, r, 1, d)[0]
+    D, I = idx.search(Q, k)
+    for j, r in enumerate(planted):
+        assert I[j, 0] == r
+    assert ((I >= 0) & (I < N)).all()
+    for b in range(B):
+        assert len(set(I[b].tolist())) == k
+        rows = np.concatenate([oracle.synth_rows(seed, int(r), 1, d) for r in I[b]])
+        np.testing.assert_array_equal(idx.get_rows(int(I[b, 0]), 1), rows[:1])
+        want = oracle.scores(rows, Q[b:b + 1])[0]
+        np.testing.assert_array_equal(D[b].view(np.uint32), want.view(np.uint32))
+        key = list(zip((-D[b]).tolist(), I[b].tolist()))
+        assert key == sorted(key)
+    rng = np.random.default_rng(0)
+    starts = rng.integers(0, N - 2000, size=100)
+    for s in starts:
+        Xs = oracle.synth_rows(seed, int(s), 2000, d)
+        Ds, Is = oracle.search(Xs, Q, 1, id_offset=int(s))
+        # the best row of the sample must not beat the k-th result unless it is in the result
+        for b in range(B):
+            if Ds[b, 0] > D[b, k - 1] or (Ds[b, 0] == D[b, k - 1] and Is[b, 0] < I[b, k - 1]):
+                assert Is[b, 0] in I[b]
+    idx.close()
