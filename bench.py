@@ -50,13 +50,16 @@ def cpu_baseline(args: argparse.Namespace) -> dict:
     from oracle import flat as oracle
 
     n = min(args.cpu_sample_rows, args.rows)
-    cores = oracle.num_threads()
+    # thread policy of the reference: faiss_threads = min(16, cores) (config/__init__.py:32-46,
+    # applied at runtime.py:76); cores = what this process may actually run on
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(16, avail, oracle.num_threads()))
     X = oracle.synth_rows(args.seed, 0, n, args.dim)
     Q = oracle.synth_rows(args.seed + 3087, 0, args.batch, args.dim)
-    oracle.search(X, Q, args.k)  # warm
+    oracle.search(X, Q, args.k, nthreads=cores)  # warm
     reps, t0 = 0, time.perf_counter()
     while True:
-        oracle.search(X, Q, args.k)
+        oracle.search(X, Q, args.k, nthreads=cores)
         reps += 1
         el = time.perf_counter() - t0
         if el > 10.0 or reps >= 20:
@@ -173,6 +176,17 @@ def main() -> None:
 
     if rank == 0:
         scan_ms = scan_ms_total / max(scan_launches, 1)
+        # HBM bytes per launch from the committed PMC pass (FETCH_SIZE, corrected as the microarch
+        # guide prescribes); only quoted when it was collected on this exact workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_scan_hbm_traffic.json")) as fh:
+                tr = json.load(fh)
+            w = tr["workload"]
+            if (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (N, d, B, k, world):
+                traffic = tr["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         alg_bytes = 4.0 * n_local * d  # corpus read once per batch, per GPU
         achieved = alg_bytes / (scan_ms * 1e-3) / 1e9
         out = {
@@ -204,7 +218,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_kernel_ms": scan_ms,
                 "launches": scan_launches,
                 "algorithmic_bytes_per_launch": alg_bytes,

@@ -15,7 +15,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
-LIB_PATH = os.path.join(_CSRC, "librag_amd.so")
+LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
 _SOURCES = ["rag_amd.hip"]
 _DEPS = ["rag_amd.hip", "flat_kernels.hip.h"]

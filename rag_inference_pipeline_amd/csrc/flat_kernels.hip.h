@@ -15,6 +15,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Experiment-only switches (scripts/tune_scan.py builds side libraries with them; never defined in
+// the product build):  RAGK_ABLATE_NO_MFMA keeps the load stream and drops the matrix work,
+// RAGK_ABLATE_L2_WINDOW keeps the matrix work and reads a cache-resident window of the corpus.
+#if defined(RAGK_ABLATE_NO_MFMA)
+#define RAGK_MFMA(x, q, acc) ([&] { asm volatile("" ::"v"(x), "v"(q)); return acc; }())
+#else
+#define RAGK_MFMA(x, q, acc) __builtin_amdgcn_mfma_f32_32x32x2f32(x, q, acc, 0, 0, 0)
+#endif
+
 namespace ragk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,7 +32,7 @@ typedef unsigned long long u64;
 
 constexpr int kQT = 32;        // queries per scan pass (MFMA N)
 constexpr int kTileRows = 32;  // corpus rows per wave tile (MFMA M)
-constexpr int kScanWaves = 8;  // waves per scan workgroup (2 per SIMD)
+constexpr int kMaxScanWaves = 16;
 constexpr int kMergeThreads = 256;
 constexpr int kMergeMaxKeys = 4096;  // keys sorted per merge workgroup (32 KiB LDS)
 
@@ -106,10 +115,12 @@ __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {
     return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16;
 }
 
-// E = buffer capacity / 64, D = register ring depth (steps of 8 columns in flight), L2 = metric.
-template <int E, int D, bool L2>
-__global__ __launch_bounds__(kScanWaves * 64) void scan_topk_kernel(const ScanParams p) {
+// NW = waves per workgroup (NW/4 per SIMD), E = buffer capacity / 64, D = register ring depth
+// (steps of 8 columns in flight per wave), L2 = metric.
+template <int NW, int E, int D, bool L2>
+__global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) {
     constexpr int C = 64 * E;
+    constexpr int kScanWaves = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,6 +158,9 @@ __global__ __launch_bounds__(kScanWaves * 64) void scan_topk_kernel(const ScanPa
     const int tiles_per_iter = gridDim.x * kScanWaves;
     int tile = blockIdx.x * kScanWaves + wave;
     auto row_ptr = [&](int t) -> const float* {
+#if defined(RAGK_ABLATE_L2_WINDOW)
+        t &= 31;
+#endif
         long long row = (long long)t * kTileRows + r;
         row = row < last_row ? row : last_row;
         return p.X + row * p.row_stride + 4 * h;
@@ -171,27 +185,35 @@ __global__ __launch_bounds__(kScanWaves * 64) void scan_topk_kernel(const ScanPa
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-        // One step = 8 columns: 4 MFMAs on ring slot i, then the slot is refilled D steps ahead and
-        // the next step's query fragment is fetched from LDS.  sched_barrier pins that order: left
-        // alone hipcc sinks all D refills to the end of the unrolled body, where the first one is
-        // waited for immediately.
+        // One step = 8 columns = 4 MFMAs on ring slot i.  The ring is refilled G slots at a time,
+        // D steps ahead: with G = 4 the four loads that make up one 128-byte line of each of the
+        // wave's 32 rows are issued back to back, which is what lets the vector L1 fetch each
+        // line once (measured: spread one per step the same stream runs at half the rate).
+        // sched_group_barrier pins {next query fragment, 4 MFMA} per step and the refills at the
+        // end of their group; left alone hipcc sinks all refills to the end of the unrolled body.
+        constexpr int G = D >= 4 ? 4 : D;
         f32x4 qcur = qf[lane];
         int s0 = 0;
         for (; s0 < S - D; s0 += D) {
             const float* src = pc + 8 * (s0 + D);
             const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const f32x4 qn = qs[i * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][0], qcur[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][1], qcur[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][2], qcur[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][3], qcur[3], acc, 0, 0, 0);
-                xb[i] = *reinterpret_cast<const f32x4*>(src + 8 * i);
-                qcur = qn;
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ring refill (VMEM read)
+            for (int g = 0; g < D; g += G) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int i = g + j;
+                    const f32x4 qn = qs[i * 64];
+                    acc = RAGK_MFMA(xb[i][0], qcur[0], acc);
+                    acc = RAGK_MFMA(xb[i][1], qcur[1], acc);
+                    acc = RAGK_MFMA(xb[i][2], qcur[2], acc);
+                    acc = RAGK_MFMA(xb[i][3], qcur[3], acc);
+                    qcur = qn;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(src + 8 * (g + j));
+                __builtin_amdgcn_sched_group_barrier(0x020, G, 0);  // ring refill (VMEM reads)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -199,18 +221,23 @@ __global__ __launch_bounds__(kScanWaves * 64) void scan_topk_kernel(const ScanPa
         {
             const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                // the fragment after the last step is never used; stay inside the Q image
-                const f32x4 qn = qs[(i + 1 < D ? i : -1 - s0) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][0], qcur[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][1], qcur[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][2], qcur[2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[i][3], qcur[3], acc, 0, 0, 0);
-                xb[i] = *reinterpret_cast<const f32x4*>(pn + 8 * i);
-                qcur = qn;
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // ring refill (VMEM read)
+            for (int g = 0; g < D; g += G) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int i = g + j;
+                    // the fragment after the last step is never used; stay inside the Q image
+                    const f32x4 qn = qs[(i + 1 < D ? i : -1 - s0) * 64];
+                    acc = RAGK_MFMA(xb[i][0], qcur[0], acc);
+                    acc = RAGK_MFMA(xb[i][1], qcur[1], acc);
+                    acc = RAGK_MFMA(xb[i][2], qcur[2], acc);
+                    acc = RAGK_MFMA(xb[i][3], qcur[3], acc);
+                    qcur = qn;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(pn + 8 * (g + j));
+                __builtin_amdgcn_sched_group_barrier(0x020, G, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

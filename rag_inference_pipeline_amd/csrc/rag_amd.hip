@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -79,28 +80,50 @@ int pick_ring(int S) {
         if (S % dpt == 0 && S >= dpt) return dpt;
     return 1;
 }
+bool ring_ok(int S, int ring) {
+    return (ring == 1 || ring == 2 || ring == 4 || ring == 8 || ring == 12 || ring == 16) && S % ring == 0 && S >= ring;
+}
 
 using ScanFn = void (*)(const ragk::ScanParams);
 
-template <int E, int D>
+template <int NW, int E, int D>
 ScanFn scan_fn_metric(bool l2) {
-    return l2 ? (ScanFn)ragk::scan_topk_kernel<E, D, true> : (ScanFn)ragk::scan_topk_kernel<E, D, false>;
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<NW, E, D, true> : (ScanFn)ragk::scan_topk_kernel<NW, E, D, false>;
 }
-template <int E>
+template <int NW, int E>
 ScanFn scan_fn_ring(int ring, bool l2) {
     switch (ring) {
-        case 8: return scan_fn_metric<E, 8>(l2);
-        case 4: return scan_fn_metric<E, 4>(l2);
-        case 2: return scan_fn_metric<E, 2>(l2);
-        default: return scan_fn_metric<E, 1>(l2);
+#ifdef RAGK_TUNING
+        case 16: return scan_fn_metric<NW, E, 16>(l2);
+        case 12: return scan_fn_metric<NW, E, 12>(l2);
+#endif
+        case 8: return scan_fn_metric<NW, E, 8>(l2);
+        case 4: return scan_fn_metric<NW, E, 4>(l2);
+        case 2: return scan_fn_metric<NW, E, 2>(l2);
+        default: return scan_fn_metric<NW, E, 1>(l2);
     }
 }
-ScanFn scan_fn(int cap, int ring, bool l2) {
+template <int NW>
+ScanFn scan_fn_cap(int cap, int ring, bool l2) {
     switch (cap) {
-        case 64: return scan_fn_ring<1>(ring, l2);
-        case 128: return scan_fn_ring<2>(ring, l2);
-        default: return scan_fn_ring<4>(ring, l2);
+        case 64: return scan_fn_ring<NW, 1>(ring, l2);
+        case 128: return scan_fn_ring<NW, 2>(ring, l2);
+        default: return scan_fn_ring<NW, 4>(ring, l2);
     }
+}
+ScanFn scan_fn(int waves, int cap, int ring, bool l2) {
+    switch (waves) {
+#ifdef RAGK_TUNING  // measured on 10M x 768: 8 waves x ring 8 is as fast as any of these
+        case 16: return scan_fn_cap<16>(cap, ring, l2);
+        case 12: return scan_fn_cap<12>(cap, ring, l2);
+#endif
+        default: return scan_fn_cap<8>(cap, ring, l2);
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 }  // namespace
@@ -212,13 +235,22 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
         return fail(RAG_ERR_UNSUPPORTED, "k=%d with d=%d exceeds the fused scan kernel's LDS budget (max k %d)", k, h->d,
                     rag_index_max_k(h->d, nq));
     const int S = h->d8 / 8;
-    const int ring = pick_ring(S);
+    int ring = pick_ring(S);
+    int waves = 8;
+#ifdef RAGK_TUNING
+    {   // tuning overrides (scripts/tune_scan.py builds a side library with -DRAGK_TUNING)
+        const int w = env_int("RAG_AMD_SCAN_WAVES", 0);
+        if (w == 8 || w == 12 || w == 16) waves = w;
+        const int rg = env_int("RAG_AMD_SCAN_RING", 0);
+        if (ring_ok(S, rg)) ring = rg;
+    }
+#endif
     const bool l2 = h->metric == RAG_METRIC_L2;
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
     const int n_tiles = (int)n_tiles_ll;
-    int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + kScanWaves - 1) / kScanWaves);
+    int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + waves - 1) / waves);
     grid = std::max(grid, 1);
-    const int n_iters = (n_tiles + grid * kScanWaves - 1) / (grid * kScanWaves);
+    const int n_iters = (n_tiles + grid * waves - 1) / (grid * waves);
 
     int rc = ensure_search_ws(h, nq, k, grid);
     if (rc) return rc;
@@ -241,7 +273,7 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
     sp.k = k;
     sp.n_tiles = n_tiles;
     sp.n_iters = n_iters;
-    ScanFn fn = scan_fn(cap, ring, l2);
+    ScanFn fn = scan_fn(waves, cap, ring, l2);
     const size_t lds = scan_lds_bytes(h->d8, cap);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
@@ -251,7 +283,7 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kScanWaves * 64), lds, st, sp);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
     HIP_TRY(hipGetLastError());
     if (h->prof) {
         HIP_TRY(hipEventRecord(e1, st));
