@@ -90,54 +90,46 @@ def main() -> None:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the retrieval path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsal) ranks share devices
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("RAG_AMD_DIST_BACKEND", "nccl")  # "gloo": host-staged rehearsal
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
 
-    from rag_inference_pipeline_amd.flat_index import FlatIndex, merge_topk_device
+    from rag_inference_pipeline_amd.flat_index import FlatIndex
+    from rag_inference_pipeline_amd.sharded import ShardedFlatIndex, shard_range
     from oracle import flat as oracle  # query generator + cpu_baseline only (checker side)
 
     N, d, B, k = args.rows, args.dim, args.batch, args.k
-    row_lo, row_hi = N * rank // world, N * (rank + 1) // world
+    row_lo, row_hi = shard_range(N, rank, world)
     n_local = row_hi - row_lo
 
-    index = FlatIndex(d, device=local_rank)
+    index = FlatIndex(d, device=dev)
     index.reserve(n_local)
     index.add_synthetic(n_local, seed=args.seed, row_number_offset=row_lo)
     index.set_id_offset(row_lo)
+    sharded = ShardedFlatIndex(index, metric=0, device=dev) if world > 1 else None
 
-    stream = torch.cuda.current_stream()
-    sptr = stream.cuda_stream
+    sptr = torch.cuda.current_stream().cuda_stream
     Q = torch.from_numpy(oracle.synth_rows(args.seed + 3087, 0, B, d)).cuda()
     out_s = torch.empty((B, k), dtype=torch.float32, device="cuda")
     out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
-    if world > 1:
-        # one all-gather per batch: [scores f32 | ids i64] packed per rank
-        pack = torch.empty(B * k * 12, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * B * k * 12, dtype=torch.uint8, device="cuda")
-        all_s = torch.empty((world, B, k), dtype=torch.float32, device="cuda")
-        all_i = torch.empty((world, B, k), dtype=torch.int64, device="cuda")
-        fin_s = torch.empty((B, k), dtype=torch.float32, device="cuda")
-        fin_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
-        pack_s = pack[: B * k * 4].view(torch.float32).view(B, k)
-        pack_i = pack[B * k * 4:].view(torch.int64).view(B, k)
+    fin = {}
 
     def step() -> None:
-        if world == 1:
+        if sharded is None:
             index.search_device(Q.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
-            return
-        index.search_device(Q.data_ptr(), B, k, pack_s.data_ptr(), pack_i.data_ptr(), sptr)
-        dist.all_gather_into_tensor(gathered, pack)
-        g = gathered.view(world, B * k * 12)
-        all_s.copy_(g[:, : B * k * 4].contiguous().view(torch.float32).view(world, B, k))
-        all_i.copy_(g[:, B * k * 4:].contiguous().view(torch.int64).view(world, B, k))
-        merge_topk_device(local_rank, 0, world, B, k, all_s.data_ptr(), all_i.data_ptr(),
-                          fin_s.data_ptr(), fin_i.data_ptr(), sptr)
+        else:
+            fin["s"], fin["i"] = sharded.search_tensors(Q, k)
 
     def barrier() -> None:
         if dist is not None:
@@ -171,8 +163,8 @@ def main() -> None:
         lat.append(time.perf_counter() - t1)
     p50_ms = float(np.median(lat) * 1e3) if lat else None
 
-    res_s = (fin_s if world > 1 else out_s).cpu().numpy()
-    res_i = (fin_i if world > 1 else out_i).cpu().numpy()
+    res_s = (fin["s"] if world > 1 else out_s).cpu().numpy()
+    res_i = (fin["i"] if world > 1 else out_i).cpu().numpy()
 
     if rank == 0:
         scan_ms = scan_ms_total / max(scan_launches, 1)

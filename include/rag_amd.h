@@ -22,7 +22,9 @@
  *     exception crosses the boundary.  rag_last_error() returns a thread-local message.
  *   - Plain pointers and sizes only.  "host" pointers are ordinary process memory; "dev"
  *     pointers are HIP device memory on the handle's device.  `stream` is a hipStream_t
- *     passed as void* (NULL = the handle's own stream).
+ *     passed as void*; work is enqueued on exactly that stream (NULL = HIP's default stream,
+ *     which is also what torch.cuda.current_stream().cuda_stream reads as by default).  The
+ *     host-pointer entry points use a private stream of the handle and block until done.
  *   - Handles are thread-safe: concurrent calls on one handle serialise on an internal mutex
  *     (the reference's BatchScheduler can have several batches in flight,
  *     services/gateway/batch_scheduler.py:286-288).

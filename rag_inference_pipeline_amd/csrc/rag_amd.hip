@@ -149,6 +149,12 @@ struct rag_index {
     float* q_pin = nullptr; size_t q_pin_cap = 0;
     float* out_s_pin = nullptr; long long* out_i_pin = nullptr; size_t out_pin_cap = 0;
 
+    // the search workspace is shared by every stream searches are issued on: a search that
+    // follows one on a different stream first waits for ws_event
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
+
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -324,6 +330,17 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
 
 int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i,
                          hipStream_t st) {
+    if (h->ws_used && h->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    struct Mark {  // record the workspace hand-over point on every exit path
+        rag_index* h;
+        hipStream_t st;
+        ~Mark() {
+            if (hipEventRecord(h->ws_event, st) == hipSuccess) {
+                h->ws_stream = st;
+                h->ws_used = true;
+            }
+        }
+    } mark{h, st};
     if (h->n == 0) {
         const int total = nq * k;
         ragk::fill_neutral_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(out_s, out_i, total, h->metric);
@@ -387,9 +404,11 @@ extern "C" int rag_index_create(int32_t d, int32_t metric, int32_t device, rag_i
         return fail(RAG_ERR_HIP, "hipGetDeviceProperties failed");
     }
     h->n_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming) != hipSuccess) {
+        if (h->stream) (void)hipStreamDestroy(h->stream);
         delete h;
-        return fail(RAG_ERR_HIP, "hipStreamCreate failed");
+        return fail(RAG_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     }
     *out = h;
     return RAG_OK;
@@ -400,7 +419,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
     {
         DeviceGuard g(h->device);
         std::lock_guard<std::mutex> lk(h->mu);
-        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        (void)hipDeviceSynchronize();
         for (auto& ev : h->prof_events) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
@@ -411,6 +430,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
         for (void* p : hptrs)
             if (p) (void)hipHostFree(p);
+        if (h->ws_event) (void)hipEventDestroy(h->ws_event);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -452,7 +472,7 @@ extern "C" int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = grow_rows(h, h->n + n);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL is HIP's default stream
     float* dst = h->X + (size_t)h->n * h->d8;
     if (h->d8 != h->d) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * h->d8 * sizeof(float), st));
     HIP_TRY(hipMemcpy2DAsync(dst, (size_t)h->d8 * sizeof(float), rows_dev, (size_t)h->d * sizeof(float),
@@ -525,7 +545,7 @@ extern "C" int rag_index_search_device(rag_index* h, const float* queries_dev, i
     if (nq == 0) return RAG_OK;
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;  // exactly the caller's stream; NULL is HIP's default stream
     return search_device_locked(h, queries_dev, nq, k, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), st);
 }
 

@@ -1,0 +1,64 @@
+"""Worker for the multi-rank tests (launched once per rank by test_sharded.py).
+
+argv: mode (cpu|gpu) rank world port out_path n d nq k metric
+  cpu: the local index is a test double backed by the ORACLE (tests may use the oracle; the product
+       path never does) and the merge is oracle.merge — this rehearses sharding, packing and the
+       gloo all-gather with no GPU.
+  gpu: the real FlatIndex and the device merge kernel; ranks share GPU 0, gather staged over gloo.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    mode, rank, world, port, out_path = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    n, d, nq, k, metric = (int(a) for a in sys.argv[6:11])
+    import torch
+    import torch.distributed as dist
+
+    from oracle import flat as oracle
+    from rag_inference_pipeline_amd.sharded import ShardedFlatIndex, shard_range
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_range(n, rank, world)
+    X_local = oracle.synth_rows(1234, lo, hi - lo, d)
+    Q = oracle.synth_rows(4321, 0, nq, d)
+
+    if mode == "cpu":
+        class OracleLocal:
+            def search_device(self, q_ptr, nq_, k_, s_ptr, i_ptr, stream=0):
+                q = np.ctypeslib.as_array(ctypes.cast(q_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, d))
+                D, I = oracle.search(X_local, q, k_, metric, id_offset=lo)
+                np.ctypeslib.as_array(ctypes.cast(s_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, k_))[:] = D
+                np.ctypeslib.as_array(ctypes.cast(i_ptr, ctypes.POINTER(ctypes.c_int64)), (nq_, k_))[:] = I
+
+        def merge(metric_, all_s, all_i, out_s, out_i):
+            D, I = oracle.merge(all_s.numpy(), all_i.numpy(), metric_)
+            out_s.copy_(torch.from_numpy(D))
+            out_i.copy_(torch.from_numpy(I))
+
+        sharded = ShardedFlatIndex(OracleLocal(), metric, device="cpu", merge=merge)
+    else:
+        from rag_inference_pipeline_amd.flat_index import FlatIndex
+
+        torch.cuda.set_device(0)
+        local = FlatIndex(d, metric, device=0)
+        local.add_synthetic(hi - lo, 1234, row_number_offset=lo)
+        local.set_id_offset(lo)
+        sharded = ShardedFlatIndex(local, metric, device=0)
+
+    D, I = sharded.search(Q, k)
+    D2, I2 = sharded.search(Q[: max(1, nq // 2)], k)  # a second shape re-uses the group
+    np.savez(out_path, D=D, I=I, D2=D2, I2=I2, lo=lo, hi=hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Multi-rank corpus sharding: world_size-2/3 gloo runs, CPU rehearsal and (gpu) the real kernels."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import flat as oracle
+from rag_inference_pipeline_amd.sharded import pack_layout, shard_range
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(mode, world, tmp_path, n, d, nq, k, metric):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"rank{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_worker.py"), mode, str(r), str(world), str(port), out,
+             str(n), str(d), str(nq), str(k), str(metric)],
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    return [np.load(o) for o in outs]
+
+
+def _check(results, n, d, nq, k, metric, world):
+    X = oracle.synth_rows(1234, 0, n, d)
+    Q = oracle.synth_rows(4321, 0, nq, d)
+    D, I = oracle.search(X, Q, k, metric)
+    D2, I2 = oracle.search(X, Q[: max(1, nq // 2)], k, metric)
+    covered = 0
+    for r, res in enumerate(results):
+        np.testing.assert_array_equal(res["I"], I)       # every rank holds the full merged answer
+        np.testing.assert_array_equal(res["D"], D)
+        np.testing.assert_array_equal(res["I2"], I2)
+        np.testing.assert_array_equal(res["D2"], D2)
+        assert (int(res["lo"]), int(res["hi"])) == shard_range(n, r, world)
+        covered += int(res["hi"]) - int(res["lo"])
+    assert covered == n
+
+
+def test_shard_ranges_partition_the_corpus():
+    for n, w in [(10_000_000, 8), (10, 3), (7, 8), (0, 2)]:
+        edges = [shard_range(n, r, w) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        sizes = [hi - lo for lo, hi in edges]
+        assert max(sizes) - min(sizes) <= 1
+    assert pack_layout(32, 10) == (1280, 3840)  # 3.84 KB per rank per batch
+
+
+@pytest.mark.parametrize("world,metric", [(2, 0), (3, 1)])
+def test_sharded_search_gloo_cpu_rehearsal(tmp_path, world, metric):
+    n, d, nq, k = 5001, 64, 9, 10
+    _check(_launch("cpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,metric,k", [(2, 0, 10), (3, 0, 100), (2, 1, 10)])
+def test_sharded_search_real_kernels_two_ranks_one_gpu(gpu_required, tmp_path, world, metric, k):
+    n, d, nq = 40_003, 384, 32
+    _check(_launch("gpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
