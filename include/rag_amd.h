@@ -10,10 +10,10 @@
  *                         load()    :40-111  (faiss.read_index + warm-up search)
  *                         search()  :113-158 (index.search(embeddings, k) -> (D, I))
  *                         unload()  :160-171, index_size :178-183
- *   rag_encoder_*    <- src/pipeline/components/embedding.py
+ *   rag_bert_*       <- src/pipeline/components/embedding.py   (query encoder)
  *                         load()    :70-98   (SentenceTransformer(name))
  *                         encode()  :100-175 (model.encode(..., normalize_embeddings=True))
- *   rag_reranker_*   <- src/pipeline/components/reranker.py
+ *                    <- src/pipeline/components/reranker.py    (cross-encoder)
  *                         load()    :71-173  (AutoModelForSequenceClassification)
  *                         rerank()  :206-272 (model(**inputs).logits -> sigmoid)
  *
@@ -133,6 +133,71 @@ int32_t rag_index_max_k(int32_t d, int32_t nq);
 int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
                           const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
                           int64_t* out_ids_dev, void* stream);
+
+/* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
+
+typedef struct rag_bert rag_bert;
+
+/* activations */
+#define RAG_ACT_GELU 1       /* exact (erf) GELU — BERT / MiniLM / bge / XLM-R default */
+#define RAG_ACT_GELU_TANH 2
+#define RAG_ACT_RELU 3
+
+/* classifier heads (for RAG_BERT_OUT_LOGITS) */
+#define RAG_HEAD_NONE 0
+#define RAG_HEAD_BERT 1      /* BertForSequenceClassification: tanh(Wp x_cls + bp) -> Wc . + bc */
+#define RAG_HEAD_ROBERTA 2   /* (XLM-)RobertaForSequenceClassification: tanh(Wd x_cls + bd) -> Wo . + bo */
+
+/* outputs of a forward pass */
+#define RAG_BERT_OUT_MEAN 0    /* nseq x hidden: mean over tokens (sentence-transformers Pooling "mean") */
+#define RAG_BERT_OUT_CLS 1     /* nseq x hidden: first token (Pooling "cls") */
+#define RAG_BERT_OUT_LOGITS 2  /* nseq x n_labels classifier logits */
+#define RAG_BERT_OUT_PROBS 3   /* nseq x n_labels sigmoid(logits) (reranker.py:252) */
+#define RAG_BERT_OUT_HIDDEN 4  /* T x hidden last hidden state (tests) */
+
+typedef struct rag_bert_config {
+    int32_t vocab_size;
+    int32_t hidden;        /* <= 1024, multiple of 32 */
+    int32_t n_layers;
+    int32_t n_heads;       /* hidden / n_heads must be 32 or 64 */
+    int32_t intermediate;  /* multiple of 32 */
+    int32_t max_positions;
+    int32_t type_vocab;    /* 0 = no token-type embedding */
+    int32_t pos_offset;    /* 0 for BERT; padding_idx + 1 (= 2) for RoBERTa-family position ids */
+    int32_t act;           /* RAG_ACT_* */
+    int32_t head;          /* RAG_HEAD_* */
+    int32_t n_labels;      /* classifier outputs (1 for the rerankers) */
+    float ln_eps;
+} rag_bert_config;
+
+/* Number of entries rag_bert_create expects in `weights` for a config:
+ *   [0] word_emb [V][H]  [1] pos_emb [P][H]  [2] type_emb [Tv][H] (NULL if type_vocab == 0)
+ *   [3] emb_ln_gamma [H] [4] emb_ln_beta [H]
+ *   per layer l, 12 entries from 5 + 12 l:
+ *     qkv_w [3H][H] (q;k;v rows) qkv_b [3H]  attn_out_w [H][H] attn_out_b [H]  ln1_gamma ln1_beta
+ *     ffn_in_w [I][H] ffn_in_b [I]  ffn_out_w [H][I] ffn_out_b [H]  ln2_gamma ln2_beta
+ *   then, if head != RAG_HEAD_NONE: head_dense_w [H][H] head_dense_b [H] head_out_w [n_labels][H] head_out_b
+ * All fp32, torch.nn.Linear layout (W[out][in], row-major), device memory on `device`.  The library
+ * does not copy them: the caller (PyTorch-ROCm tensors) keeps them alive until rag_bert_destroy. */
+int32_t rag_bert_weight_count(const rag_bert_config* cfg);
+
+int rag_bert_create(const rag_bert_config* cfg, const void* const* weights_dev, int32_t n_weights,
+                    int32_t device, rag_bert** out);
+int rag_bert_destroy(rag_bert* h);
+
+/* Forward pass over nseq PACKED sequences (no padding): sequence s owns tokens
+ * cu_seqlens[s] .. cu_seqlens[s+1]-1 of ids / type_ids (type_ids may be NULL = all zero).
+ * `out_kind` is RAG_BERT_OUT_*; `normalize` L2-normalises pooled embeddings
+ * (normalize_embeddings=True, embedding.py:132).  Host buffers; blocks until `out` is filled. */
+int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* type_ids, const int32_t* cu_seqlens,
+                     int32_t nseq, int32_t out_kind, int32_t normalize, float* out);
+
+/* Same with ids / type_ids / cu_seqlens / out in device memory (total_tokens = cu_seqlens[nseq],
+ * max_seq_len = longest sequence); asynchronous on `stream`. */
+int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* type_ids_dev,
+                            const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
+                            int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,8 +17,8 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
-_SOURCES = ["rag_amd.hip"]
-_DEPS = ["rag_amd.hip", "flat_kernels.hip.h"]
+_SOURCES = ["rag_amd.hip", "rag_bert.hip"]
+_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "rag_common.h"]
 
 RAG_OK = 0
 RAG_ERR_INVALID_ARG = 1
@@ -30,6 +30,18 @@ RAG_ERR_STATE = 6
 
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
+
+# rag_bert_config (include/rag_amd.h)
+ACT_GELU, ACT_GELU_TANH, ACT_RELU = 1, 2, 3
+HEAD_NONE, HEAD_BERT, HEAD_ROBERTA = 0, 1, 2
+BERT_OUT_MEAN, BERT_OUT_CLS, BERT_OUT_LOGITS, BERT_OUT_PROBS, BERT_OUT_HIDDEN = 0, 1, 2, 3, 4
+
+
+class BertConfigStruct(C.Structure):
+    _fields_ = [(name, C.c_int32) for name in (
+        "vocab_size", "hidden", "n_layers", "n_heads", "intermediate", "max_positions", "type_vocab",
+        "pos_offset", "act", "head", "n_labels")] + [("ln_eps", C.c_float)]
+
 
 _lib = None
 _lock = threading.Lock()
@@ -82,6 +94,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def _declare(lib: C.CDLL) -> None:
     f32p, i64p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int64), C.c_void_p
+    i32p = C.POINTER(C.c_int32)
     sig = {
         "rag_abi_version": (C.c_int, []),
         "rag_device_count": (C.c_int, []),
@@ -104,6 +117,13 @@ def _declare(lib: C.CDLL) -> None:
         "rag_index_max_k": (C.c_int32, [C.c_int32, C.c_int32]),
         "rag_merge_topk_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             vp, vp, vp, vp, vp]),
+        "rag_bert_weight_count": (C.c_int32, [C.POINTER(BertConfigStruct)]),
+        "rag_bert_create": (C.c_int, [C.POINTER(BertConfigStruct), C.POINTER(vp), C.c_int32, C.c_int32,
+                                      C.POINTER(vp)]),
+        "rag_bert_destroy": (C.c_int, [vp]),
+        "rag_bert_forward": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, f32p]),
+        "rag_bert_forward_device": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -1,0 +1,392 @@
+// bert_kernels.hip.h — gfx950 kernels of the BERT-family encoder used by the query embedder and the
+// cross-encoder reranker.
+//
+// Replaces the arithmetic behind SentenceTransformer.encode (reference
+// src/pipeline/components/embedding.py:127-133) and AutoModelForSequenceClassification.forward
+// (reference src/pipeline/components/reranker.py:248-252).  Everything is fp32: the north star asks
+// for the same doc ids as the CPU fp32 embedder, which rules out bf16/fp16 GEMMs; the GEMMs run on
+// the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (same rate as the fp32 vector peak, but
+// one VGPR per operand and the VALU left free for the epilogue).
+//
+// Sequences are PACKED: T = sum of lengths tokens, no padding rows; cu[s] .. cu[s+1] are the tokens
+// of sequence s.  All weights are torch.nn.Linear layout: W[out][in], row-major.
+//
+//   embed_ln_kernel     word + position + type embedding, LayerNorm                (1 wave / token)
+//   gemm_nt_kernel      C = A · Wᵀ + bias [+ residual] [activation], 128x128x32 tiles, fp32 MFMA
+//   attention_kernel    softmax(QKᵀ/√dh)V per (sequence, head), online softmax     (1 wave / 64 rows)
+//   layernorm_kernel    y = LN(x)                                                   (1 wave / token)
+//   pool_kernel         mean / CLS pooling + optional L2 normalisation              (1 block / seq)
+//   gather_rows_kernel  first-token rows for the classifier head
+//   head_out_kernel     logits = x · Wcᵀ + bc (tiny N), plus sigmoid
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ragb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Act { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_RELU = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_GELU_TANH: {
+            const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            return 0.5f * x * (1.0f + tanhf(u));
+        }
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+
+// ---- embeddings + LayerNorm ------------------------------------------------------------------------
+// One wave per token; H <= 64 * kMaxPerLane.
+constexpr int kMaxPerLane = 16;  // hidden size up to 1024
+
+struct EmbedParams {
+    const int* ids;        // [T]
+    const int* type_ids;   // [T] or null
+    const int* cu;         // [nseq + 1]
+    const float* word_emb; // [V][H]
+    const float* pos_emb;  // [P][H]
+    const float* type_emb; // [Tv][H] or null
+    const float* ln_g;
+    const float* ln_b;
+    float* out;            // [T][H]
+    int T, nseq, H, pos_offset, max_pos, vocab;
+    float eps;
+};
+
+__device__ __forceinline__ int find_seq(const int* cu, int nseq, int t) {
+    int lo = 0, hi = nseq;  // largest s with cu[s] <= t
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedParams p) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= p.T) return;
+    const int s = find_seq(p.cu, p.nseq, t);
+    int pos = t - p.cu[s] + p.pos_offset;
+    pos = pos < p.max_pos ? pos : p.max_pos - 1;
+    int id = p.ids[t];
+    id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
+    const int ty = p.type_ids ? p.type_ids[t] : 0;
+    const float* w = p.word_emb + (size_t)id * p.H;
+    const float* pe = p.pos_emb + (size_t)pos * p.H;
+    const float* te = p.type_emb ? p.type_emb + (size_t)ty * p.H : nullptr;
+    float v[kMaxPerLane];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        float x = 0.f;
+        if (c < p.H) {
+            x = w[c] + pe[c];
+            if (te) x += te[c];
+        }
+        v[j] = x;
+        sum += x;
+    }
+    const float mean = wave_sum(sum) / (float)p.H;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        const float dlt = c < p.H ? v[j] - mean : 0.f;
+        var += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(var) / (float)p.H + p.eps);
+    float* o = p.out + (size_t)t * p.H;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        if (c < p.H) o[c] = (v[j] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* g, const float* b, float* y, int T,
+                                                        int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const float* xi = x + (size_t)t * H;
+    float v[kMaxPerLane];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < H ? xi[c] : 0.f;
+        sum += v[j];
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        const float dlt = c < H ? v[j] - mean : 0.f;
+        var += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+    float* o = y + (size_t)t * H;
+#pragma unroll
+    for (int j = 0; j < kMaxPerLane; ++j) {
+        const int c = lane + 64 * j;
+        if (c < H) o[c] = (v[j] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+// ---- GEMM: C[M][N] = A[M][K] · W[N][K]ᵀ (+ bias[N]) (+ R[M][N]) (act) -------------------------------------
+// 128 x 128 x 32 tiles, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+// LDS rows are padded to 36 floats: a ds_read_b128 fragment read (16 lanes, 16 different rows, same
+// column) then touches 16 distinct 4-bank groups — conflict free (36 r mod 64 is a bijection on r mod 16).
+constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 36;
+
+struct GemmParams {
+    const float* A;    // [M][lda]
+    const float* W;    // [N][ldw]
+    const float* bias; // [N] or null
+    const float* R;    // [M][ldr] residual or null
+    float* C;          // [M][ldc]
+    int M, N, K;
+    int lda, ldw, ldr, ldc;
+    int act;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
+    __shared__ __attribute__((aligned(16))) float Ws[GBN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+
+    // staging map: 128 rows x 8 float4 per tile; thread -> (row = tid/8 + 32 j, float4 col = tid%8)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const float* ag[4];
+    const float* wg[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int am = m0 + srow + 32 * j;
+        am = am < p.M ? am : p.M - 1;
+        int wr = n0 + srow + 32 * j;
+        wr = wr < p.N ? wr : p.N - 1;
+        ag[j] = p.A + (size_t)am * p.lda + scol;
+        wg[j] = p.W + (size_t)wr * p.ldw + scol;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    f32x4 ra[4], rw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ra[j] = *reinterpret_cast<const f32x4*>(ag[j]);
+        rw[j] = *reinterpret_cast<const f32x4*>(wg[j]);
+    }
+
+    const int nk = p.K / GBK;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4*>(&As[(srow + 32 * j) * GLD + scol]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * j) * GLD + scol]) = rw[j];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)(kt + 1) * GBK);
+                rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)(kt + 1) * GBK);
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < GBK / 8; ++kg) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + a * 32 + r) * GLD + kg * 8 + 4 * h]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                bf[b] = *reinterpret_cast<const f32x4*>(&Ws[(wn * 64 + b * 32 + r) * GLD + kg * 8 + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane (r, h) holds column n = .. + r, rows (i&3) + 8(i>>2) + 4h of each 32x32 tile
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + r;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < p.M) {
+                    float v = acc[a][b][i] + bias;
+                    v = apply_act(v, p.act);
+                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
+                    p.C[(size_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- attention ---------------------------------------------------------------------------------------
+// qkv: [T][3H] (q | k | v, each H = heads * DH).  One wave per (sequence, head, block of 64 query rows);
+// lane = query row.  Keys/values stream through LDS in tiles of 64; online softmax in registers.
+template <int DH>
+__global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const int* cu, float* ctx, int H, int heads,
+                                                       float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[64 * DH];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * DH];
+    const int lane = threadIdx.x;
+    const int s = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    if (qb * 64 >= L) return;
+    const int qi = qb * 64 + lane;
+    const bool valid = qi < L;
+    const size_t ld = (size_t)3 * H;
+    const float* qrow = qkv + (size_t)(t0 + (valid ? qi : L - 1)) * ld + head * DH;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int c = 0; c < DH; c += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(qrow + c);
+        q[c] = v[0] * scale; q[c + 1] = v[1] * scale; q[c + 2] = v[2] * scale; q[c + 3] = v[3] * scale;
+        o[c] = o[c + 1] = o[c + 2] = o[c + 3] = 0.f;
+    }
+    float mx = -__builtin_inff(), den = 0.f;
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        const int nj = min(64, L - j0);
+        __syncthreads();
+        // stage K/V tile: 64 keys x DH floats each, lane-strided float4 copies
+        for (int idx = lane; idx < nj * (DH / 4); idx += 64) {
+            const int j = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
+            const float* base = qkv + (size_t)(t0 + j0 + j) * ld + head * DH + c;
+            *reinterpret_cast<f32x4*>(&Ks[j * DH + c]) = *reinterpret_cast<const f32x4*>(base + H);
+            *reinterpret_cast<f32x4*>(&Vs[j * DH + c]) = *reinterpret_cast<const f32x4*>(base + 2 * H);
+        }
+        __syncthreads();
+        for (int j = 0; j < nj; ++j) {
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[j * DH + c]);  // broadcast read
+                sc = __builtin_fmaf(q[c], kv[0], sc);
+                sc = __builtin_fmaf(q[c + 1], kv[1], sc);
+                sc = __builtin_fmaf(q[c + 2], kv[2], sc);
+                sc = __builtin_fmaf(q[c + 3], kv[3], sc);
+            }
+            const float mnew = fmaxf(mx, sc);
+            const float alpha = __expf(mx - mnew);  // exp(-inf) = 0 on the first key
+            const float pj = __expf(sc - mnew);
+            den = den * alpha + pj;
+#pragma unroll
+            for (int c = 0; c < DH; c += 4) {
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[j * DH + c]);
+                o[c] = __builtin_fmaf(o[c], alpha, pj * vv[0]);
+                o[c + 1] = __builtin_fmaf(o[c + 1], alpha, pj * vv[1]);
+                o[c + 2] = __builtin_fmaf(o[c + 2], alpha, pj * vv[2]);
+                o[c + 3] = __builtin_fmaf(o[c + 3], alpha, pj * vv[3]);
+            }
+            mx = mnew;
+        }
+    }
+    if (valid) {
+        const float inv = 1.0f / den;
+        float* orow = ctx + (size_t)(t0 + qi) * H + head * DH;
+#pragma unroll
+        for (int c = 0; c < DH; c += 4) {
+            f32x4 v = {o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
+            *reinterpret_cast<f32x4*>(orow + c) = v;
+        }
+    }
+}
+
+// ---- pooling ----------------------------------------------------------------------------------------
+// mode 0: mean over the sequence's tokens, mode 1: first token.  normalize: divide by the L2 norm
+// (torch.nn.functional.normalize: x / max(||x||, 1e-12)).
+__global__ __launch_bounds__(256) void pool_kernel(const float* x, const int* cu, float* out, int H, int mode,
+                                                   int normalize) {
+    __shared__ float red[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    float v[4];  // H <= 1024: 4 columns per thread
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 256 * j;
+        float a = 0.f;
+        if (c < H) {
+            if (mode == 0) {
+                for (int t = 0; t < L; ++t) a += x[(size_t)(t0 + t) * H + c];
+                a /= (float)L;
+            } else {
+                a = x[(size_t)t0 * H + c];
+            }
+        }
+        v[j] = a;
+        ss += a * a;
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = normalize ? 1.0f / fmaxf(sqrtf(tot), 1e-12f) : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + 256 * j;
+        if (c < H) out[(size_t)s * H + c] = v[j] * inv;
+    }
+}
+
+__global__ void gather_rows_kernel(const float* x, const int* cu, float* out, int nseq, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseq * H) return;
+    const int s = i / H, c = i - s * H;
+    out[i] = x[(size_t)cu[s] * H + c];
+}
+
+// logits[s][j] = x[s] · Wc[j] + bc[j]; one wave per (s, j).  probs = sigmoid(logits) when requested.
+__global__ __launch_bounds__(64) void head_out_kernel(const float* x, const float* Wc, const float* bc, float* logits,
+                                                      float* probs, int H, int n_labels) {
+    const int s = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    float a = 0.f;
+    for (int c = lane; c < H; c += 64) a = __builtin_fmaf(x[(size_t)s * H + c], Wc[(size_t)j * H + c], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+        const float z = a + (bc ? bc[j] : 0.f);
+        logits[(size_t)s * n_labels + j] = z;
+        if (probs) probs[(size_t)s * n_labels + j] = 1.0f / (1.0f + expf(-z));
+    }
+}
+
+}  // namespace ragb

@@ -15,18 +15,13 @@
 #include <vector>
 
 #include "flat_kernels.hip.h"
+#include "rag_common.h"
 
 namespace {
 
 thread_local char g_err[512] = "";
 
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
+#define fail ragc_fail
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -127,6 +122,14 @@ int env_int(const char* name, int dflt) {
 }
 
 }  // namespace
+
+int ragc_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 struct rag_index {
     int device = 0;

@@ -1,0 +1,323 @@
+// rag_bert.hip — C ABI (rag_bert_* in include/rag_amd.h) over the kernels in bert_kernels.hip.h.
+// Runs a BERT-family encoder over packed sequences: the query embedder (mean / CLS pooling +
+// L2 normalisation) and the cross-encoder reranker (classifier head + sigmoid).
+// Weights stay in caller-owned device memory (PyTorch-ROCm tensors); this file owns only the
+// activation workspace.  No CPU compute path.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "bert_kernels.hip.h"
+#include "rag_common.h"
+
+namespace {
+
+constexpr int kPerLayer = 12;
+constexpr int kEmbEntries = 5;
+
+int weight_count(const rag_bert_config& c) {
+    return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0);
+}
+
+int map_act(int act) {
+    switch (act) {
+        case RAG_ACT_GELU: return ragb::ACT_GELU_ERF;
+        case RAG_ACT_GELU_TANH: return ragb::ACT_GELU_TANH;
+        case RAG_ACT_RELU: return ragb::ACT_RELU;
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+struct rag_bert {
+    rag_bert_config cfg{};
+    int device = 0;
+    std::vector<const float*> w;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // activation workspace, sized for ws_tokens tokens / ws_seqs sequences
+    long long ws_tokens = 0, ws_seqs = 0;
+    float *x = nullptr, *y = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr;
+    float *pooled = nullptr, *pooled2 = nullptr, *logits = nullptr, *probs = nullptr;
+    // host-path staging
+    int *ids_dev = nullptr, *types_dev = nullptr, *cu_dev = nullptr;
+    long long ids_cap = 0, types_cap = 0, cu_cap = 0;
+    float* out_dev = nullptr;
+    long long out_cap = 0;
+};
+
+namespace {
+
+template <typename T>
+int grow(T** p, long long* cap, long long want) {
+    if (want <= *cap) return RAG_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), (size_t)want * sizeof(T)));
+    *cap = want;
+    return RAG_OK;
+}
+
+int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
+    const rag_bert_config& c = h->cfg;
+    if (tokens > h->ws_tokens) {
+        float** bufs[] = {&h->x, &h->y, &h->qkv, &h->ctx, &h->ffn};
+        for (float** b : bufs) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
+        h->ws_tokens = 0;
+        const long long t = tokens + tokens / 8;
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->x), (size_t)t * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y), (size_t)t * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qkv), (size_t)t * 3 * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ctx), (size_t)t * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ffn), (size_t)t * c.intermediate * sizeof(float)));
+        h->ws_tokens = t;
+    }
+    if (nseq > h->ws_seqs) {
+        float** bufs[] = {&h->pooled, &h->pooled2, &h->logits, &h->probs};
+        for (float** b : bufs) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
+        h->ws_seqs = 0;
+        const long long s = nseq + nseq / 8;
+        const int nl = std::max(1, c.n_labels);
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pooled), (size_t)s * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->pooled2), (size_t)s * c.hidden * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->logits), (size_t)s * nl * sizeof(float)));
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->probs), (size_t)s * nl * sizeof(float)));
+        h->ws_seqs = s;
+    }
+    return RAG_OK;
+}
+
+int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
+                int ldc, int M, int N, int K, int act, hipStream_t st) {
+    if (M <= 0) return RAG_OK;
+    ragb::GemmParams g;
+    g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
+    g.act = act;
+    dim3 grid((N + ragb::GBN - 1) / ragb::GBN, (M + ragb::GBM - 1) / ragb::GBM);
+    ragb::gemm_nt_kernel<<<grid, dim3(256), 0, st>>>(g);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+size_t out_elems(const rag_bert_config& c, int out_kind, long long nseq, long long tokens) {
+    switch (out_kind) {
+        case RAG_BERT_OUT_MEAN:
+        case RAG_BERT_OUT_CLS: return (size_t)nseq * c.hidden;
+        case RAG_BERT_OUT_LOGITS:
+        case RAG_BERT_OUT_PROBS: return (size_t)nseq * std::max(1, c.n_labels);
+        case RAG_BERT_OUT_HIDDEN: return (size_t)tokens * c.hidden;
+        default: return 0;
+    }
+}
+
+int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu, int nseq, int T, int max_len,
+                   int out_kind, int normalize, float* out, hipStream_t st) {
+    using namespace ragb;
+    const rag_bert_config& c = h->cfg;
+    const int H = c.hidden, I = c.intermediate, heads = c.n_heads, dh = H / heads;
+    int rc = ensure_ws(h, T, nseq);
+    if (rc) return rc;
+    const float* const* w = h->w.data();
+
+    EmbedParams ep;
+    ep.ids = ids; ep.type_ids = c.type_vocab > 0 ? types : nullptr; ep.cu = cu;
+    ep.word_emb = w[0]; ep.pos_emb = w[1]; ep.type_emb = c.type_vocab > 0 ? w[2] : nullptr;
+    ep.ln_g = w[3]; ep.ln_b = w[4];
+    ep.out = h->x;
+    ep.T = T; ep.nseq = nseq; ep.H = H; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
+    ep.vocab = c.vocab_size; ep.eps = c.ln_eps;
+    embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
+    RAGC_HIP_TRY(hipGetLastError());
+
+    const int act = map_act(c.act);
+    const float scale = 1.0f / sqrtf((float)dh);
+    const dim3 agrid((max_len + 63) / 64, heads, nseq);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const float* const* lw = w + kEmbEntries + kPerLayer * l;
+        // QKV projection
+        rc = launch_gemm(h->x, H, lw[0], H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
+        if (rc) return rc;
+        if (dh == 32)
+            attention_kernel<32><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        else
+            attention_kernel<64><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        RAGC_HIP_TRY(hipGetLastError());
+        // attention output projection + residual, LayerNorm
+        rc = launch_gemm(h->ctx, H, lw[2], H, lw[3], h->x, H, h->y, H, T, H, H, ACT_NONE, st);
+        if (rc) return rc;
+        layernorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->y, lw[4], lw[5], h->x, T, H, c.ln_eps);
+        RAGC_HIP_TRY(hipGetLastError());
+        // feed-forward: act(x W1ᵀ + b1) W2ᵀ + b2 + residual, LayerNorm
+        rc = launch_gemm(h->x, H, lw[6], H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
+        if (rc) return rc;
+        rc = launch_gemm(h->ffn, I, lw[8], I, lw[9], h->x, H, h->y, H, T, H, I, ACT_NONE, st);
+        if (rc) return rc;
+        layernorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->y, lw[10], lw[11], h->x, T, H, c.ln_eps);
+        RAGC_HIP_TRY(hipGetLastError());
+    }
+
+    switch (out_kind) {
+        case RAG_BERT_OUT_HIDDEN:
+            RAGC_HIP_TRY(hipMemcpyAsync(out, h->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+            break;
+        case RAG_BERT_OUT_MEAN:
+        case RAG_BERT_OUT_CLS:
+            pool_kernel<<<dim3(nseq), dim3(256), 0, st>>>(h->x, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
+            RAGC_HIP_TRY(hipGetLastError());
+            break;
+        case RAG_BERT_OUT_LOGITS:
+        case RAG_BERT_OUT_PROBS: {
+            const float* const* hw = w + kEmbEntries + kPerLayer * c.n_layers;
+            const int total = nseq * H;
+            gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
+            RAGC_HIP_TRY(hipGetLastError());
+            rc = launch_gemm(h->pooled, H, hw[0], H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
+            if (rc) return rc;
+            const bool probs = out_kind == RAG_BERT_OUT_PROBS;
+            head_out_kernel<<<dim3(nseq, c.n_labels), dim3(64), 0, st>>>(h->pooled2, hw[2], hw[3], probs ? h->logits : out,
+                                                                        probs ? out : nullptr, H, c.n_labels);
+            RAGC_HIP_TRY(hipGetLastError());
+            break;
+        }
+        default: return ragc_fail(RAG_ERR_INVALID_ARG, "unknown out_kind %d", out_kind);
+    }
+    return RAG_OK;
+}
+
+int check_forward(const rag_bert* h, int nseq, int out_kind) {
+    if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
+    if (nseq <= 0) return ragc_fail(RAG_ERR_INVALID_ARG, "nseq=%d out of range", nseq);
+    if (out_kind < RAG_BERT_OUT_MEAN || out_kind > RAG_BERT_OUT_HIDDEN)
+        return ragc_fail(RAG_ERR_INVALID_ARG, "unknown out_kind %d", out_kind);
+    if ((out_kind == RAG_BERT_OUT_LOGITS || out_kind == RAG_BERT_OUT_PROBS) && h->cfg.head == RAG_HEAD_NONE)
+        return ragc_fail(RAG_ERR_STATE, "model was created without a classifier head");
+    return RAG_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t rag_bert_weight_count(const rag_bert_config* cfg) { return cfg ? weight_count(*cfg) : 0; }
+
+extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* weights_dev, int32_t n_weights,
+                               int32_t device, rag_bert** out) {
+    if (!out) return ragc_fail(RAG_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (!cfg || !weights_dev) return ragc_fail(RAG_ERR_INVALID_ARG, "null config or weight table");
+    const rag_bert_config& c = *cfg;
+    if (c.hidden <= 0 || c.hidden > 64 * ragb::kMaxPerLane || c.hidden % 32)
+        return ragc_fail(RAG_ERR_UNSUPPORTED, "hidden=%d (need a multiple of 32, <= 1024)", c.hidden);
+    if (c.n_heads <= 0 || c.hidden % c.n_heads || (c.hidden / c.n_heads != 32 && c.hidden / c.n_heads != 64))
+        return ragc_fail(RAG_ERR_UNSUPPORTED, "head dim %d (need 32 or 64)", c.n_heads > 0 ? c.hidden / c.n_heads : 0);
+    if (c.intermediate <= 0 || c.intermediate % 32)
+        return ragc_fail(RAG_ERR_UNSUPPORTED, "intermediate=%d (need a multiple of 32)", c.intermediate);
+    if (c.n_layers <= 0 || c.vocab_size <= 0 || c.max_positions <= 0 || c.type_vocab < 0)
+        return ragc_fail(RAG_ERR_INVALID_ARG, "bad model dimensions");
+    if (map_act(c.act) < 0) return ragc_fail(RAG_ERR_INVALID_ARG, "unknown activation %d", c.act);
+    if (c.head < RAG_HEAD_NONE || c.head > RAG_HEAD_ROBERTA) return ragc_fail(RAG_ERR_INVALID_ARG, "unknown head %d", c.head);
+    if (c.head != RAG_HEAD_NONE && c.n_labels <= 0) return ragc_fail(RAG_ERR_INVALID_ARG, "n_labels must be positive");
+    if (n_weights != weight_count(c))
+        return ragc_fail(RAG_ERR_INVALID_ARG, "expected %d weight pointers, got %d", weight_count(c), n_weights);
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights_dev[i] && !(i == 2 && c.type_vocab == 0))
+            return ragc_fail(RAG_ERR_INVALID_ARG, "weight pointer %d is null", i);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ragc_fail(RAG_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return ragc_fail(RAG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    RagcDeviceGuard g(device);
+    if (!g.ok) return ragc_fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    rag_bert* h = new (std::nothrow) rag_bert();
+    if (!h) return ragc_fail(RAG_ERR_OOM, "host allocation failed");
+    h->cfg = c;
+    h->device = device;
+    h->w.assign(reinterpret_cast<const float* const*>(weights_dev), reinterpret_cast<const float* const*>(weights_dev) + n_weights);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        return ragc_fail(RAG_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = h;
+    return RAG_OK;
+}
+
+extern "C" int rag_bert_destroy(rag_bert* h) {
+    if (!h) return RAG_OK;
+    {
+        RagcDeviceGuard g(h->device);
+        std::lock_guard<std::mutex> lk(h->mu);
+        (void)hipDeviceSynchronize();
+        void* ptrs[] = {h->x, h->y, h->qkv, h->ctx, h->ffn, h->pooled, h->pooled2, h->logits, h->probs,
+                        h->ids_dev, h->types_dev, h->cu_dev, h->out_dev};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+    return RAG_OK;
+}
+
+extern "C" int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* type_ids_dev,
+                                       const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
+                                       int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
+                                       void* stream) {
+    int rc = check_forward(h, nseq, out_kind);
+    if (rc) return rc;
+    if (!ids_dev || !cu_seqlens_dev || !out_dev || total_tokens <= 0 || max_seq_len <= 0)
+        return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer or empty batch");
+    RagcDeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    return forward_locked(h, ids_dev, type_ids_dev, cu_seqlens_dev, nseq, total_tokens, max_seq_len, out_kind, normalize,
+                          out_dev, (hipStream_t)stream);
+}
+
+extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* type_ids, const int32_t* cu_seqlens,
+                                int32_t nseq, int32_t out_kind, int32_t normalize, float* out) {
+    int rc = check_forward(h, nseq, out_kind);
+    if (rc) return rc;
+    if (!ids || !cu_seqlens || !out) return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer");
+    if (cu_seqlens[0] != 0) return ragc_fail(RAG_ERR_INVALID_ARG, "cu_seqlens[0] must be 0");
+    int max_len = 0;
+    for (int s = 0; s < nseq; ++s) {
+        const int len = cu_seqlens[s + 1] - cu_seqlens[s];
+        if (len <= 0) return ragc_fail(RAG_ERR_INVALID_ARG, "sequence %d is empty", s);
+        if (len + h->cfg.pos_offset > h->cfg.max_positions)
+            return ragc_fail(RAG_ERR_INVALID_ARG, "sequence %d has %d tokens; the model holds %d positions", s, len,
+                             h->cfg.max_positions - h->cfg.pos_offset);
+        max_len = std::max(max_len, len);
+    }
+    const int T = cu_seqlens[nseq];
+    RagcDeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    rc = grow(&h->ids_dev, &h->ids_cap, (long long)T);
+    if (rc) return rc;
+    if (type_ids) {
+        rc = grow(&h->types_dev, &h->types_cap, (long long)T);
+        if (rc) return rc;
+    }
+    rc = grow(&h->cu_dev, &h->cu_cap, (long long)nseq + 1);
+    if (rc) return rc;
+    const size_t n_out = out_elems(h->cfg, out_kind, nseq, T);
+    rc = grow(&h->out_dev, &h->out_cap, (long long)n_out);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    RAGC_HIP_TRY(hipMemcpyAsync(h->ids_dev, ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    if (type_ids) RAGC_HIP_TRY(hipMemcpyAsync(h->types_dev, type_ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->cu_dev, cu_seqlens, (size_t)(nseq + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind, normalize,
+                        h->out_dev, st);
+    if (rc) return rc;
+    RAGC_HIP_TRY(hipMemcpyAsync(out, h->out_dev, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    RAGC_HIP_TRY(hipStreamSynchronize(st));
+    return RAG_OK;
+}

@@ -1,0 +1,105 @@
+"""GPU parity: HIP transformer (rag_bert_* through the C ABI) vs the torch-CPU oracle.
+Tolerances (fp32 everywhere; accumulation order and exp/erf/tanh/rsqrt implementations differ
+between the GPU and libm): hidden states 5e-5 abs on O(1) activations, unit-norm embeddings 1e-5,
+sigmoid scores 1e-5."""
+import numpy as np
+import pytest
+
+from oracle import bert as obert
+from rag_inference_pipeline_amd.bert import BertConfig, BertModel, random_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _seqs(rng, lengths, vocab):
+    return [rng.integers(3, vocab, size=int(n)).tolist() for n in lengths]
+
+
+def _small(cfg: BertConfig, vocab=2000) -> BertConfig:
+    cfg.vocab_size = vocab  # the embedding table is the only thing that scales with the vocabulary
+    return cfg
+
+
+def test_minilm_hidden_states_and_mean_pooling(gpu_required):
+    cfg = _small(BertConfig.minilm_l6())
+    w = random_weights(cfg, 0)
+    model = BertModel(cfg, w)
+    rng = np.random.default_rng(0)
+    seqs = _seqs(rng, [1, 2, 8, 13, 20, 63, 64, 65, 130], cfg.vocab_size)
+    types = [[0] * len(s) for s in seqs]
+    got = model.hidden_states(seqs, types)
+    want = np.concatenate(obert.hidden_states(cfg, w, seqs, types))
+    np.testing.assert_allclose(got, want, atol=5e-5, rtol=1e-4)
+    emb = model.embed(seqs, types)
+    np.testing.assert_allclose(emb, obert.embed(cfg, w, seqs, types), atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(emb, axis=1), 1.0, atol=1e-5)
+    raw = model.embed(seqs, types, normalize=False)
+    np.testing.assert_allclose(raw, obert.embed(cfg, w, seqs, types, normalize=False), atol=5e-5, rtol=1e-4)
+    model.close()
+
+
+def test_bge_base_cls_pooling_batch_of_32_queries(gpu_required):
+    cfg = _small(BertConfig.bge_base())
+    w = random_weights(cfg, 1)
+    model = BertModel(cfg, w)
+    rng = np.random.default_rng(1)
+    seqs = _seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size)  # query-like lengths
+    emb = model.embed(seqs)
+    assert emb.shape == (32, 768) and emb.dtype == np.float32
+    np.testing.assert_allclose(emb, obert.embed(cfg, w, seqs), atol=1e-5)
+    model.close()
+
+
+def test_cross_encoder_bert_head_scores_and_order(gpu_required):
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    w = random_weights(cfg, 2)
+    w["head_out_w"] = (w["head_out_w"] * 20).astype(np.float32)  # spread the logits so sigmoid is not flat
+    model = BertModel(cfg, w)
+    rng = np.random.default_rng(2)
+    seqs = _seqs(rng, rng.integers(24, 65, size=100), cfg.vocab_size)  # 100 (query, doc) pairs
+    types = [[0] * 10 + [1] * (len(s) - 10) for s in seqs]
+    probs = model.classify(seqs, types)
+    want = obert.classify(cfg, w, seqs, types)
+    np.testing.assert_allclose(probs, want, atol=1e-5)
+    logits = model.classify(seqs, types, sigmoid=False)
+    np.testing.assert_allclose(logits, obert.classify(cfg, w, seqs, types, sigmoid=False), atol=1e-4, rtol=1e-4)
+    # the order the reranker returns: identical unless two oracle scores are closer than the tolerance
+    o_gpu, o_cpu = obert.rerank_order(probs[:, 0].tolist()), obert.rerank_order(want[:, 0].tolist())
+    gaps = np.abs(np.diff(np.sort(want[:, 0])))
+    if gaps.min() > 2e-5:
+        assert o_gpu == o_cpu
+    model.close()
+
+
+def test_xlm_roberta_head_and_position_offset_long_sequences(gpu_required):
+    cfg = BertConfig(vocab_size=3000, hidden=768, n_layers=2, n_heads=12, intermediate=3072, max_positions=514,
+                     type_vocab=1, pos_offset=2, head="roberta", n_labels=1, ln_eps=1e-5)
+    w = random_weights(cfg, 3)
+    model = BertModel(cfg, w)
+    rng = np.random.default_rng(3)
+    seqs = _seqs(rng, [512, 300, 7], cfg.vocab_size)  # 512 = truncate_length, the reference maximum
+    np.testing.assert_allclose(model.classify(seqs, sigmoid=False), obert.classify(cfg, w, seqs, sigmoid=False),
+                               atol=2e-4, rtol=1e-4)
+    model.close()
+
+
+def test_bert_error_contract(gpu_required):
+    from rag_inference_pipeline_amd import _native
+    cfg = _small(BertConfig.minilm_l6(), vocab=100)
+    w = random_weights(cfg, 4)
+    model = BertModel(cfg, w)
+    with pytest.raises(_native.RagAmdError, match="classifier head"):
+        model.classify([[1, 2, 3]])
+    with pytest.raises(_native.RagAmdError, match="positions"):
+        model.embed([list(range(3, 90)) * 7])  # 609 tokens > 512 positions
+    with pytest.raises(_native.RagAmdError, match="empty"):
+        model.embed([[1, 2], []])
+    bad = dict(w)
+    del bad["layer0.qkv_w"]
+    with pytest.raises(KeyError):
+        BertModel(cfg, bad)
+    with pytest.raises(_native.RagAmdError, match="head dim"):
+        BertModel(BertConfig(vocab_size=50, hidden=96, n_layers=1, n_heads=2, intermediate=64, max_positions=16),
+                  random_weights(BertConfig(vocab_size=50, hidden=96, n_layers=1, n_heads=2, intermediate=64,
+                                            max_positions=16), 0))
+    model.close()
