@@ -140,6 +140,13 @@ def lib() -> C.CDLL:
                 raise NativeLibraryError(
                     f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(there is no CPU fallback)")
+            # PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  Two runtimes in one process do
+            # not share a device ("No HIP GPUs are available" from whichever initialises second), so
+            # torch's copy is mapped first and librag_amd.so binds to it by SONAME.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
             try:
                 handle = C.CDLL(LIB_PATH)
             except OSError as e:  # e.g. libamdhip64 missing

@@ -1,0 +1,119 @@
+"""Reranker — drop-in for the reference's cross-encoder component, on the HIP transformer.
+
+Same surface and error contract as the reference class (src/pipeline/components/reranker.py:37-308;
+messages pinned by tests/test_components.py:387 and tests/test_generation_service.py:217):
+
+    Reranker(settings).load() / .rerank(query, documents, top_n=None) -> list[RerankedDocument]
+    .rerank_batch(queries, documents_batch, top_n=None) / .unload() / .is_loaded
+
+`rerank` reproduces :237-272: pairs [query, doc.content] -> tokenizer(truncation, max_length =
+settings.truncate_length) -> classifier logit -> sigmoid -> stable descending sort -> [:top_n].
+Differences, all on the side of the hardware: the pairs of a whole BATCH of queries go through one
+packed forward pass (the reference loops over queries, :303-306, and pads each to its longest pair);
+arithmetic is fp32 (the reference uses fp16 on a GPU, :91-93).
+"""
+
+from __future__ import annotations
+
+import gc
+import logging
+import time
+
+from ..bert import iter_token_budget
+from ..config import PipelineSettings
+from .schemas import Document, RerankedDocument
+
+logger = logging.getLogger(__name__)
+
+_MAX_TOKENS_PER_PASS = 131072
+
+
+class Reranker:
+    def __init__(self, settings: PipelineSettings) -> None:
+        self.settings = settings
+        self.model_name = settings.reranker_model_name
+        self.device = f"cuda:{int(getattr(settings, 'gpu_device', 0))}"
+        self.tokenizer = None
+        self.model = None
+        self._max_len = 512
+        self._loaded = False
+        logger.info("Reranker initialized (device: %s)", self.device)
+
+    def load(self) -> None:
+        if self._loaded:
+            logger.warning("Reranker already loaded")
+            return
+        logger.info("Loading reranker model: %s", self.model_name)
+        t0 = time.time()
+        try:
+            from ..bert import BertModel
+            from ..model_source import resolve_model
+
+            cfg, weights, tokenizer, max_len = resolve_model(self.model_name, "reranker")
+            self.model = BertModel(cfg, weights, device=int(getattr(self.settings, "gpu_device", 0)))
+            self.tokenizer, self._max_len = tokenizer, max_len
+            self._loaded = True
+            self._score_pairs(["query " * 10], ["document " * 100])  # warm-up (:156-166)
+            logger.info("Reranker model loaded in %.2f seconds", time.time() - t0)
+        except Exception:
+            logger.exception("Failed to load reranker model")
+            self.model = None
+            self.tokenizer = None
+            self._loaded = False
+            raise
+
+    def unload(self) -> None:
+        if not self._loaded:
+            return
+        logger.info("Unloading reranker model")
+        if self.model is not None:
+            self.model.close()
+        self.model = None
+        self.tokenizer = None
+        gc.collect()
+        self._loaded = False
+
+    @property
+    def is_loaded(self) -> bool:
+        return self._loaded
+
+    def _score_pairs(self, queries: list[str], docs: list[str]) -> list[float]:
+        max_len = min(int(self.settings.truncate_length), self._max_len)
+        ids, types = self.tokenizer.encode_pairs(queries, docs, max_len)
+        use_types = types if self.model.cfg.type_vocab > 1 else None
+        scores: list[float] = []
+        for lo, hi in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):
+            probs = self.model.classify(ids[lo:hi], use_types[lo:hi] if use_types is not None else None, sigmoid=True)
+            scores.extend(float(p) for p in probs[:, 0])
+        return scores
+
+    @staticmethod
+    def _ranked(documents: list[Document], scores: list[float], top_n: int | None) -> list[RerankedDocument]:
+        scored = [RerankedDocument(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category,
+                                   score=float(s)) for d, s in zip(documents, scores)]
+        scored.sort(key=lambda x: x.score, reverse=True)  # stable: ties keep retrieval order
+        return scored[: len(documents) if top_n is None else top_n]
+
+    def rerank(self, query: str, documents: list[Document], top_n: int | None = None) -> list[RerankedDocument]:
+        if not self._loaded or self.model is None or self.tokenizer is None:
+            raise RuntimeError("Reranker model not loaded")
+        if not documents:
+            return []
+        scores = self._score_pairs([query] * len(documents), [d.content for d in documents])
+        return self._ranked(documents, scores, top_n)
+
+    def rerank_batch(self, queries: list[str], documents_batch: list[list[Document]],
+                     top_n: int | None = None) -> list[list[RerankedDocument]]:
+        if not self._loaded or self.model is None or self.tokenizer is None:
+            raise RuntimeError("Reranker model not loaded")
+        if len(queries) != len(documents_batch):
+            raise ValueError(
+                f"Queries ({len(queries)}) and documents ({len(documents_batch)}) must have same length")
+        flat_q = [q for q, docs in zip(queries, documents_batch) for _ in docs]
+        flat_d = [d.content for docs in documents_batch for d in docs]
+        scores = self._score_pairs(flat_q, flat_d) if flat_d else []
+        out, pos = [], 0
+        for docs in documents_batch:
+            out.append(self._ranked(docs, scores[pos:pos + len(docs)], top_n) if docs else [])
+            pos += len(docs)
+        return out

@@ -1,0 +1,108 @@
+"""CPU: component contracts that need no GPU (error messages pinned by the reference's tests),
+tokenisation, model-name resolution."""
+import numpy as np
+import pytest
+
+from rag_inference_pipeline_amd.cache import LRUCache
+from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+from rag_inference_pipeline_amd.components.reranker import Reranker
+from rag_inference_pipeline_amd.components.schemas import Document
+from rag_inference_pipeline_amd.config import PipelineSettings
+from rag_inference_pipeline_amd.model_source import HashTokenizer, HFTokenizer, resolve_model
+
+VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "what", "is", "the", "capital", "of", "france", "paris",
+         "a", "city", "in", ".", "?", "##s", "river", "long"]
+
+
+def make_tokenizer_dir(path):
+    (path / "vocab.txt").write_text("\n".join(VOCAB) + "\n")
+    (path / "tokenizer_config.json").write_text('{"tokenizer_class": "BertTokenizer", "do_lower_case": true}')
+    return str(path)
+
+
+def test_embedding_generator_contract_before_load():
+    g = EmbeddingGenerator(PipelineSettings(embedding_model_name="synthetic:all-MiniLM-L6-v2"))
+    assert g.is_loaded is False and "not loaded" in repr(g)
+    with pytest.raises(RuntimeError, match="not loaded"):
+        g.encode(["x"])
+    g._is_loaded, g._model = True, object()
+    with pytest.raises(ValueError, match="empty"):
+        g.encode([])
+    g._is_loaded, g._model = False, None
+    g.unload()
+    g.clear_cache()
+
+
+def test_reranker_contract_before_load_and_length_check():
+    r = Reranker(PipelineSettings(reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2"))
+    assert r.is_loaded is False
+    with pytest.raises(RuntimeError, match="not loaded"):
+        r.rerank("q", [Document(doc_id=1, title="t", content="c")])
+    with pytest.raises(RuntimeError, match="not loaded"):
+        r.rerank_batch(["q"], [[]])
+    r._loaded, r.model, r.tokenizer = True, object(), object()
+    assert r.rerank("q", []) == []
+    with pytest.raises(ValueError, match="must have same length"):
+        r.rerank_batch(["a", "b"], [[]])
+    assert r.rerank_batch(["a"], [[]]) == [[]]
+
+
+def test_ranked_is_stable_and_top_n():
+    docs = [Document(doc_id=i, title="", content=str(i)) for i in range(4)]
+    out = Reranker._ranked(docs, [0.2, 0.9, 0.2, 0.5], None)
+    assert [d.doc_id for d in out] == [1, 3, 0, 2] and out[0].score == pytest.approx(0.9)
+    assert [d.doc_id for d in Reranker._ranked(docs, [0.2, 0.9, 0.2, 0.5], 2)] == [1, 3]
+
+
+def test_resolve_model_never_downloads_and_knows_presets():
+    with pytest.raises(RuntimeError, match="never downloads"):
+        resolve_model("BAAI/definitely-not-cached-model", "embedding")
+    with pytest.raises(ValueError, match="unknown synthetic architecture"):
+        resolve_model("synthetic:nope", "embedding")
+    with pytest.raises(ValueError, match="no classifier head"):
+        resolve_model("synthetic:all-MiniLM-L6-v2", "reranker")
+    cfg, w, tok, max_len = resolve_model("synthetic:bge-reranker-base:3", "reranker")
+    assert (cfg.hidden, cfg.pos_offset, cfg.head, cfg.vocab_size) == (768, 2, "roberta", 250002)
+    assert w["word_emb"].shape == (250002, 768) and max_len == 512 and tok.roberta
+
+
+def test_hash_tokenizer_framing_and_truncation():
+    t = HashTokenizer(30522)
+    ids, types = t.encode_batch(["Hello, world!", ""], 16)
+    assert ids[0][0] == 101 and ids[0][-1] == 102 and len(ids[0]) == 6 and ids[1] == [101, 102]
+    assert t.encode_batch(["hello"], 8)[0] == t.encode_batch(["HELLO"], 8)[0]
+    ids, types = t.encode_pairs(["what is x"], ["x is a thing . " * 10], 16)
+    assert len(ids[0]) == 16 and types[0] == [0] * 5 + [1] * 11 and ids[0].count(102) == 2
+    r = HashTokenizer(250002, roberta=True)
+    ids, types = r.encode_pairs(["a b"], ["c"], 32)
+    assert ids[0][0] == 0 and ids[0][3:5] == [2, 2] and ids[0][-1] == 2 and set(types[0]) == {0}
+
+
+def test_hf_tokenizer_from_local_files_matches_reference_call(tmp_path):
+    transformers = pytest.importorskip("transformers")
+    path = make_tokenizer_dir(tmp_path)
+    tok = HFTokenizer(path)
+    ref = transformers.AutoTokenizer.from_pretrained(path, local_files_only=True)
+    texts = ["What is the capital of France?", "Paris."]
+    ids, types = tok.encode_batch(texts, 16)
+    assert ids == ref(texts, truncation=True, max_length=16)["input_ids"]
+    assert ids[0][0] == 2 and ids[0][-1] == 3
+    q, d = ["what is the capital of france ?"] * 2, ["paris is a city in france .", "the river is long . " * 20]
+    pids, ptypes = tok.encode_pairs(q, d, 24)
+    enc = ref([[a, b] for a, b in zip(q, d)], padding=True, truncation=True, max_length=24)  # reranker.py:240-246
+    for i in range(2):
+        n = sum(enc["attention_mask"][i])
+        assert pids[i] == enc["input_ids"][i][:n] and ptypes[i] == enc["token_type_ids"][i][:n]
+    assert len(pids[1]) == 24
+
+
+def test_lru_cache_ttl_and_eviction():
+    c = LRUCache(capacity=2, ttl=None)
+    c.put("a", 1); c.put("b", 2); assert c.get("a") == 1
+    c.put("c", 3)
+    assert c.get("b") is None and c.get("a") == 1 and c.get("c") == 3 and len(c) == 2
+    c.clear(); assert len(c) == 0
+    c = LRUCache(capacity=2, ttl=0.0)
+    c.put("x", np.ones(2))
+    import time; time.sleep(0.01)
+    assert c.get("x") is None

@@ -74,3 +74,145 @@ def test_faiss_only_profile_end_to_end(gpu_required, corpus, tmp_path):
         np.testing.assert_array_equal(np.array([d.score for d in item.docs], np.float32), Do[i])
     registry.unload_all()
     assert not registry.get("faiss_store").is_loaded
+
+
+# ---- embedder / reranker / whole retrieval node --------------------------------------------------------
+
+def _hf_checkpoint(tmp_path, head):
+    """A tiny BERT checkpoint + WordPiece vocabulary written with `transformers` itself."""
+    import torch
+    import transformers
+    from test_components_cpu import VOCAB, make_tokenizer_dir
+
+    torch.manual_seed(0)
+    cfg = transformers.BertConfig(vocab_size=len(VOCAB), hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                                  intermediate_size=128, max_position_embeddings=64, num_labels=1)
+    model = (transformers.BertForSequenceClassification(cfg) if head else transformers.BertModel(cfg, add_pooling_layer=False)).eval()
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1)
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    d = tmp_path / ("ce" if head else "st")
+    d.mkdir()
+    model.save_pretrained(str(d))
+    make_tokenizer_dir(d)
+    return str(d), model, transformers.AutoTokenizer.from_pretrained(str(d), local_files_only=True)
+
+
+def test_embedding_generator_from_local_checkpoint_matches_transformers(gpu_required, tmp_path):
+    """The reference's embed path restated with `transformers` on the CPU: tokenizer -> BertModel ->
+    mean pooling -> normalize (what SentenceTransformer.encode(normalize_embeddings=True) does)."""
+    import torch
+    from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+    path, model, tok = _hf_checkpoint(tmp_path, head=False)
+    gen = EmbeddingGenerator(PipelineSettings(embedding_model_name=path, DISABLE_CACHE_FOR_PROFILING="true"))
+    gen.load()
+    texts = ["What is the capital of France?", "paris is a city in france.", "the river is long", "?"]
+    emb = gen.encode(texts)
+    enc = tok(texts, padding=True, truncation=True, return_tensors="pt")
+    with torch.no_grad():
+        h = model(**enc).last_hidden_state
+    m = enc["attention_mask"][..., None].float()
+    want = torch.nn.functional.normalize((h * m).sum(1) / m.sum(1), dim=1).numpy()
+    assert emb.shape == (4, 64) and emb.dtype == np.float32
+    np.testing.assert_allclose(emb, want, atol=1e-5)
+    # cache path returns the same rows and hits on the second call
+    gen2 = EmbeddingGenerator(PipelineSettings(embedding_model_name=path, DISABLE_CACHE_FOR_PROFILING="false"))
+    gen2.load()
+    a, b = gen2.encode(texts), gen2.encode(texts[::-1])
+    np.testing.assert_array_equal(a, b[::-1])
+    assert gen2.cache.hits >= 4
+    gen.unload(); gen2.unload()
+    assert not gen.is_loaded
+
+
+def test_reranker_from_local_checkpoint_matches_transformers(gpu_required, tmp_path):
+    import torch
+    from rag_inference_pipeline_amd.components.reranker import Reranker
+    from rag_inference_pipeline_amd.components.schemas import Document
+    path, model, tok = _hf_checkpoint(tmp_path, head=True)
+    rr = Reranker(PipelineSettings(reranker_model_name=path, truncate_length=32))
+    rr.load()
+    docs = [Document(doc_id=i, title=f"t{i}", content=c) for i, c in enumerate(
+        ["paris is the capital of france.", "the river is long. " * 12, "a city", "what?", "france"])]
+    query = "what is the capital of france?"
+    got = rr.rerank(query, docs)
+    enc = tok([[query, d.content] for d in docs], padding=True, truncation=True, return_tensors="pt", max_length=32)
+    with torch.no_grad():
+        want = torch.sigmoid(model(**enc).logits.view(-1).float()).numpy()
+    order = sorted(range(len(docs)), key=lambda i: want[i], reverse=True)
+    assert [d.doc_id for d in got] == order
+    np.testing.assert_allclose([d.score for d in got], want[order], atol=1e-5)
+    assert [d.doc_id for d in rr.rerank(query, docs, top_n=2)] == order[:2]
+    both = rr.rerank_batch([query, "a city in france"], [docs, docs[:3]])
+    assert [d.doc_id for d in both[0]] == order and len(both[1]) == 3
+    rr.unload()
+
+
+def test_retriever_with_rerank_profile_end_to_end(gpu_required, tmp_path):
+    """configs/retriever_with_rerank.yaml shape on synthetic models: text in, reranked documents out;
+    every stage checked against the oracle restatement of the same stage."""
+    import sqlite3
+    from oracle import bert as obert
+    from rag_inference_pipeline_amd.model_source import resolve_model
+
+    n_docs, d = 2000, 384
+    words = ["alpha", "beta", "gamma", "delta", "river", "city", "france", "paris", "long", "capital", "model", "index"]
+    rng = np.random.default_rng(0)
+    contents = [" ".join(rng.choice(words, size=int(rng.integers(8, 25)))) for _ in range(n_docs)]
+    emb_name, rr_name = "synthetic:all-MiniLM-L6-v2:7", "synthetic:ms-marco-MiniLM-L-6-v2:8"
+    ecfg, ew, etok, emax = resolve_model(emb_name, "embedding")
+    # corpus embeddings come from the ORACLE encoder (index building is not the path under test)
+    ids, types = etok.encode_batch(contents, emax)
+    X = np.concatenate([obert.embed(ecfg, ew, ids[i:i + 250], types[i:i + 250]) for i in range(0, n_docs, 250)])
+    index_path = tmp_path / "faiss_index.bin"
+    index_io.write_flat_index(index_path, X, 0)
+    docs_dir = tmp_path / "documents"
+    docs_dir.mkdir()
+    con = sqlite3.connect(docs_dir / "documents.db")
+    con.execute("CREATE TABLE documents (doc_id INTEGER PRIMARY KEY, title TEXT, content TEXT, category TEXT)")
+    con.executemany("INSERT INTO documents VALUES (?,?,?,?)", [(i, f"Doc {i}", c, "cat") for i, c in enumerate(contents)])
+    con.commit(); con.close()
+    prof = tmp_path / "retriever_with_rerank.yaml"
+    prof.write_text("---\nname: retrieval_with_rerank\ncomponents:\n  - name: embedding_generator\n    type: embedding\n"
+                    "  - name: faiss_store\n    type: faiss\n  - name: document_store\n    type: document_store\n"
+                    "  - name: reranker\n    type: reranker\nroutes:\n  - prefix: /retrieve\n    target: retrieval\n")
+    settings = PipelineSettings(FAISS_INDEX_PATH=str(index_path), DOCUMENTS_DIR=str(docs_dir), faiss_dim=d,
+                                ROLE_PROFILE_OVERRIDE_PATH=str(prof), DOCUMENTS_PAYLOAD_MODE="full",
+                                DISABLE_CACHE_FOR_PROFILING="true", embedding_model_name=emb_name,
+                                reranker_model_name=rr_name, retrieval_k=10, retrieval_batch_size=8,
+                                retrieval_max_batch_delay_ms=20)
+    registry, _, _ = runtime_factory.build_registry_from_profile(settings)
+    queries = ["capital of france", "long river city", "model index alpha beta", "paris", "gamma delta gamma"]
+
+    async def run():
+        ex = RetrievalExecutor(registry, settings)
+        await ex.start()
+        outs = await asyncio.gather(*[ex.process_request(RetrievalRequestItem(request_id=f"r{i}", query=q))
+                                      for i, q in enumerate(queries)])
+        await ex.stop()
+        return outs
+
+    outs = asyncio.run(run())
+    # oracle pipeline: embed -> search -> rerank
+    qids, qtypes = etok.encode_batch(queries, emax)
+    Qo = obert.embed(ecfg, ew, qids, qtypes)
+    Do, Io = oracle.search(X, Qo, 10)
+    rcfg, rw, rtok, rmax = resolve_model(rr_name, "reranker")
+    for qi, item in enumerate(outs):
+        got_ids = [d.doc_id for d in item.docs]
+        s64 = X.astype(np.float64) @ Qo[qi].astype(np.float64)
+        gap = np.sort(s64)[::-1][9] - np.sort(s64)[::-1][10]
+        if gap > 1e-5:  # away from a near-tie at the k boundary the retrieved SET must be identical
+            assert sorted(got_ids) == sorted(Io[qi].tolist())
+        pids, ptypes = rtok.encode_pairs([queries[qi]] * 10, [contents[i] for i in Io[qi]], min(512, rmax))
+        want = obert.classify(rcfg, rw, pids, ptypes)[:, 0]
+        by_id = {int(i): float(s) for i, s in zip(Io[qi], want)}
+        for ddoc in item.docs:
+            if ddoc.doc_id in by_id:
+                assert ddoc.score == pytest.approx(by_id[ddoc.doc_id], abs=2e-5)
+            assert ddoc.content == contents[ddoc.doc_id][:512] and ddoc.title == f"Doc {ddoc.doc_id}"
+        scores = [dd.score for dd in item.docs]
+        assert scores == sorted(scores, reverse=True) and len(item.docs) == 10
+    asyncio.run(registry.stop_all())
+    registry.unload_all()
