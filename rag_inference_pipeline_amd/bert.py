@@ -283,6 +283,17 @@ class BertModel:
                                                  out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def forward_device(self, ids_ptr: int, types_ptr: int, cu_ptr: int, nseq: int, total_tokens: int,
+                       max_seq_len: int, out_kind: int, normalize: bool, out_ptr: int, stream: int = 0) -> None:
+        """Asynchronous forward on device buffers (int32 ids / types / cu_seqlens, fp32 out); pointers as
+        ints, `stream` a hipStream_t.  types_ptr may be 0."""
+        if not self._h:
+            raise RuntimeError("BertModel is closed")
+        _native.check(self._lib.rag_bert_forward_device(
+            self._h, C.c_void_p(ids_ptr), C.c_void_p(types_ptr or None), C.c_void_p(cu_ptr), int(nseq),
+            int(total_tokens), int(max_seq_len), int(out_kind), 1 if normalize else 0, C.c_void_p(out_ptr),
+            C.c_void_p(stream)))
+
     def embed(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None,
               normalize: bool = True, pooling: str | None = None) -> np.ndarray:
         """(n, hidden) sentence embeddings: pooled last hidden state, L2-normalised by default."""

@@ -14,7 +14,7 @@
 //   embed_ln_kernel     word + position + type embedding, LayerNorm                (1 wave / token)
 //   gemm_nt_kernel      C = A · Wᵀ + bias [+ residual] [activation], 128x128x32 tiles, fp32 MFMA
 //   attention_kernel    softmax(QKᵀ/√dh)V per (sequence, head), online softmax     (1 wave / 64 rows)
-//   layernorm_kernel    y = LN(x)                                                   (1 wave / token)
+//   splitk_bias_res_ln  y = LN(sum of split-K slabs + bias + residual)              (1 wave / token)
 //   pool_kernel         mean / CLS pooling + optional L2 normalisation              (1 block / seq)
 //   gather_rows_kernel  first-token rows for the classifier head
 //   head_out_kernel     logits = x · Wcᵀ + bc (tiny N), plus sigmoid
@@ -49,8 +49,8 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 }
 
 // ---- embeddings + LayerNorm ------------------------------------------------------------------------
-// One wave per token; H <= 64 * kMaxPerLane.
-constexpr int kMaxPerLane = 16;  // hidden size up to 1024
+// One wave per token, each lane owns float4 chunks lane, lane+64, ... of the row (H <= 1024, H % 4 == 0).
+constexpr int kMaxChunks = 4;  // 64 lanes * 4 chunks * 4 floats = 1024
 
 struct EmbedParams {
     const int* ids;        // [T]
@@ -75,6 +75,40 @@ __device__ __forceinline__ int find_seq(const int* cu, int nseq, int t) {
     return lo;
 }
 
+// Normalise the row held in v[] (chunk j valid when lane + 64 j < H/4) and store it.
+__device__ __forceinline__ void ln_store(f32x4 (&v)[kMaxChunks], int lane, int H, float eps, const float* g,
+                                         const float* b, float* o) {
+    const int nch = H >> 2;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j)
+        if (lane + 64 * j < nch) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    const float mean = wave_sum(sum) / (float)H;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j)
+        if (lane + 64 * j < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = v[j][e] - mean;
+                var = __builtin_fmaf(dlt, dlt, var);
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nch) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * ch);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(b + 4 * ch);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
+            *reinterpret_cast<f32x4*>(o + 4 * ch) = y;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedParams p) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -88,176 +122,207 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedParams p) {
     const float* w = p.word_emb + (size_t)id * p.H;
     const float* pe = p.pos_emb + (size_t)pos * p.H;
     const float* te = p.type_emb ? p.type_emb + (size_t)ty * p.H : nullptr;
-    float v[kMaxPerLane];
-    float sum = 0.f;
+    const int nch = p.H >> 2;
+    f32x4 v[kMaxChunks];
 #pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        float x = 0.f;
-        if (c < p.H) {
-            x = w[c] + pe[c];
-            if (te) x += te[c];
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int ch = lane + 64 * j;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (ch < nch) {
+            x = *reinterpret_cast<const f32x4*>(w + 4 * ch) + *reinterpret_cast<const f32x4*>(pe + 4 * ch);
+            if (te) x += *reinterpret_cast<const f32x4*>(te + 4 * ch);
         }
         v[j] = x;
-        sum += x;
     }
-    const float mean = wave_sum(sum) / (float)p.H;
-    float var = 0.f;
-#pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        const float dlt = c < p.H ? v[j] - mean : 0.f;
-        var += dlt * dlt;
-    }
-    const float rstd = rsqrtf(wave_sum(var) / (float)p.H + p.eps);
-    float* o = p.out + (size_t)t * p.H;
-#pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        if (c < p.H) o[c] = (v[j] - mean) * rstd * p.ln_g[c] + p.ln_b[c];
-    }
-}
-
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* g, const float* b, float* y, int T,
-                                                        int H, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= T) return;
-    const float* xi = x + (size_t)t * H;
-    float v[kMaxPerLane];
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        v[j] = c < H ? xi[c] : 0.f;
-        sum += v[j];
-    }
-    const float mean = wave_sum(sum) / (float)H;
-    float var = 0.f;
-#pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        const float dlt = c < H ? v[j] - mean : 0.f;
-        var += dlt * dlt;
-    }
-    const float rstd = rsqrtf(wave_sum(var) / (float)H + eps);
-    float* o = y + (size_t)t * H;
-#pragma unroll
-    for (int j = 0; j < kMaxPerLane; ++j) {
-        const int c = lane + 64 * j;
-        if (c < H) o[c] = (v[j] - mean) * rstd * g[c] + b[c];
-    }
+    ln_store(v, lane, p.H, p.eps, p.ln_g, p.ln_b, p.out + (size_t)t * p.H);
 }
 
 // ---- GEMM: C[M][N] = A[M][K] · W[N][K]ᵀ (+ bias[N]) (+ R[M][N]) (act) -------------------------------------
-// 128 x 128 x 32 tiles, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+// (64·TM) x (64·TN) x 32 tiles, 4 waves (2 x 2), each wave TM x TN MFMA tiles of 32 x 32:
+//   TM = TN = 2: 128 x 128 tiles for big M (cross-encoder: M = all tokens of all pairs);
+//   TM = TN = 1:  64 x 64 tiles for small M (32 queries ≈ 450 tokens) so the grid still fills 256 CUs,
+//                 with split-K over blockIdx.z writing fp32 partial slabs (no epilogue) that
+//                 splitk_bias_res_ln_kernel reduces in a fixed order.
 // LDS rows are padded to 36 floats: a ds_read_b128 fragment read (16 lanes, 16 different rows, same
 // column) then touches 16 distinct 4-bank groups — conflict free (36 r mod 64 is a bijection on r mod 16).
-constexpr int GBM = 128, GBN = 128, GBK = 32, GLD = 36;
+constexpr int GBK = 32, GLD = 36;
 
 struct GemmParams {
     const float* A;    // [M][lda]
     const float* W;    // [N][ldw]
     const float* bias; // [N] or null
     const float* R;    // [M][ldr] residual or null
-    float* C;          // [M][ldc]
+    float* C;          // [M][ldc]; with split-K: [splits][M][ldc] partial slabs
     int M, N, K;
     int lda, ldw, ldr, ldc;
     int act;
+    int k_per_split;   // K range of one blockIdx.z (multiple of 32); == K when not split
 };
 
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
-    __shared__ __attribute__((aligned(16))) float Ws[GBN * GLD];
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ __attribute__((aligned(16))) float As[BM * GLD];
+    __shared__ __attribute__((aligned(16))) float Ws[BN * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const bool split = gridDim.z > 1;
 
-    // staging map: 128 rows x 8 float4 per tile; thread -> (row = tid/8 + 32 j, float4 col = tid%8)
+    // staging map: rows x 8 float4 per tile; thread -> (row = tid/8 + 32 j, float4 col = tid%8)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const float* ag[4];
-    const float* wg[4];
+    const float* ag[2 * TM];
+    const float* wg[2 * TN];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * TM; ++j) {
         int am = m0 + srow + 32 * j;
         am = am < p.M ? am : p.M - 1;
+        ag[j] = p.A + (size_t)am * p.lda + kbeg + scol;
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j) {
         int wr = n0 + srow + 32 * j;
         wr = wr < p.N ? wr : p.N - 1;
-        ag[j] = p.A + (size_t)am * p.lda + scol;
-        wg[j] = p.W + (size_t)wr * p.ldw + scol;
+        wg[j] = p.W + (size_t)wr * p.ldw + kbeg + scol;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-    f32x4 ra[4], rw[4];
+    // Register staging.  Small tiles run two K-tiles ahead: while tile kt is multiplied out of LDS, tiles
+    // kt+1 and kt+2 are in flight (16 MFMAs per wave per tile do not cover an HBM/L2 round trip at the
+    // low occupancy small-M grids run at).
+    const int nk = (kend - kbeg) / GBK;
+    f32x4 ra0[2 * TM], rw0[2 * TN], ra1[2 * TM], rw1[2 * TN];
+    auto load_tile = [&](f32x4 (&ra)[2 * TM], f32x4 (&rw)[2 * TN], int kt) {
+        if (kt < nk) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ra[j] = *reinterpret_cast<const f32x4*>(ag[j]);
-        rw[j] = *reinterpret_cast<const f32x4*>(wg[j]);
-    }
-
-    const int nk = p.K / GBK;
-    for (int kt = 0; kt < nk; ++kt) {
+            for (int j = 0; j < 2 * TM; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)kt * GBK);
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)kt * GBK);
+        }
+    };
+    auto stage_tile = [&](const f32x4 (&ra)[2 * TM], const f32x4 (&rw)[2 * TN]) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<f32x4*>(&As[(srow + 32 * j) * GLD + scol]) = ra[j];
-            *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * j) * GLD + scol]) = rw[j];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
+        for (int j = 0; j < 2 * TM; ++j) *reinterpret_cast<f32x4*>(&As[(srow + 32 * j) * GLD + scol]) = ra[j];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)(kt + 1) * GBK);
-                rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)(kt + 1) * GBK);
-            }
-        }
+        for (int j = 0; j < 2 * TN; ++j) *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * j) * GLD + scol]) = rw[j];
+        __syncthreads();
+    };
+    auto multiply_tile = [&]() {
 #pragma unroll
         for (int kg = 0; kg < GBK / 8; ++kg) {
-            f32x4 af[2], bf[2];
+            f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + a * 32 + r) * GLD + kg * 8 + 4 * h]);
+            for (int a = 0; a < TM; ++a)
+                af[a] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 * TM + a * 32 + r) * GLD + kg * 8 + 4 * h]);
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                bf[b] = *reinterpret_cast<const f32x4*>(&Ws[(wn * 64 + b * 32 + r) * GLD + kg * 8 + 4 * h]);
+            for (int b = 0; b < TN; ++b)
+                bf[b] = *reinterpret_cast<const f32x4*>(&Ws[(wn * 32 * TN + b * 32 + r) * GLD + kg * 8 + 4 * h]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+        }
+    };
+    if constexpr (TM * TN == 1) {
+        load_tile(ra0, rw0, 0);
+        load_tile(ra1, rw1, 1);
+        for (int kt = 0; kt < nk; kt += 2) {
+            stage_tile(ra0, rw0);
+            load_tile(ra0, rw0, kt + 2);
+            multiply_tile();
+            if (kt + 1 < nk) {  // block-uniform
+                stage_tile(ra1, rw1);
+                load_tile(ra1, rw1, kt + 3);
+                multiply_tile();
+            }
+        }
+    } else {
+        // big tiles: 64 MFMAs per wave per K-tile and 2-3 workgroups per CU already cover the loads;
+        // the second register set only costs occupancy (measured: 203 VGPRs, 0.65x the throughput)
+        load_tile(ra0, rw0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            stage_tile(ra0, rw0);
+            load_tile(ra0, rw0, kt + 1);
+            multiply_tile();
         }
     }
 
     // epilogue: lane (r, h) holds column n = .. + r, rows (i&3) + 8(i>>2) + 4h of each 32x32 tile
+    float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wn * 64 + b * 32 + r;
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * 32 * TN + b * 32 + r;
         if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float bias = (!split && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int m = m0 + wm * 32 * TM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                 if (m < p.M) {
-                    float v = acc[a][b][i] + bias;
-                    v = apply_act(v, p.act);
-                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
-                    p.C[(size_t)m * p.ldc + n] = v;
+                    float v = acc[a][b][i];
+                    if (!split) {
+                        v = apply_act(v + bias, p.act);
+                        if (p.R) v += p.R[(size_t)m * p.ldr + n];
+                    }
+                    Cz[(size_t)m * p.ldc + n] = v;
                 }
             }
         }
     }
+}
+
+// y[t] = LayerNorm( sum_z part[z][t] + bias + R[t] ): reduces split-K slabs in slab order (a fixed
+// summation order), adds bias and residual, normalises.  One wave per token.  With splits == 1 and
+// bias == R == null it is the plain LayerNorm of a finished GEMM output.  All slab loads of a chunk
+// are issued before the first add (they are independent; a runtime-length loop would serialise them).
+constexpr int kMaxSplitK = 8;
+
+__global__ __launch_bounds__(256) void splitk_bias_res_ln_kernel(const float* part, int splits, const float* bias,
+                                                                 const float* R, const float* g, const float* b,
+                                                                 float* y, int T, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int nch = H >> 2;
+    const size_t slab = (size_t)T * H;
+    f32x4 v[kMaxChunks];
+#pragma unroll
+    for (int j = 0; j < kMaxChunks; ++j) {
+        const int ch = lane + 64 * j;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (ch < nch) {
+            const float* src = part + (size_t)t * H + 4 * ch;
+            f32x4 pz[kMaxSplitK];
+#pragma unroll
+            for (int z = 0; z < kMaxSplitK; ++z)
+                pz[z] = z < splits ? *reinterpret_cast<const f32x4*>(src + z * slab) : x;
+            f32x4 bb = x, rr = x;
+            if (bias) bb = *reinterpret_cast<const f32x4*>(bias + 4 * ch);
+            if (R) rr = *reinterpret_cast<const f32x4*>(R + (size_t)t * H + 4 * ch);
+            x = pz[0];
+#pragma unroll
+            for (int z = 1; z < kMaxSplitK; ++z) x += pz[z];
+            x += bb;
+            x += rr;
+        }
+        v[j] = x;
+    }
+    ln_store(v, lane, H, eps, g, b, y + (size_t)t * H);
 }
 
 // ---- attention ---------------------------------------------------------------------------------------
@@ -306,8 +371,8 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const i
                 sc = __builtin_fmaf(q[c + 3], kv[3], sc);
             }
             const float mnew = fmaxf(mx, sc);
-            const float alpha = __expf(mx - mnew);  // exp(-inf) = 0 on the first key
-            const float pj = __expf(sc - mnew);
+            const float alpha = expf(mx - mnew);  // exp(-inf) = 0 on the first key
+            const float pj = expf(sc - mnew);
             den = den * alpha + pj;
 #pragma unroll
             for (int c = 0; c < DH; c += 4) {

@@ -35,6 +35,7 @@ int map_act(int act) {
 struct rag_bert {
     rag_bert_config cfg{};
     int device = 0;
+    int n_cus = 256;
     std::vector<const float*> w;
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -73,7 +74,8 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
         h->ws_tokens = 0;
         const long long t = tokens + tokens / 8;
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->x), (size_t)t * c.hidden * sizeof(float)));
-        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y), (size_t)t * c.hidden * sizeof(float)));
+        // y doubles as the split-K slab area of the small-M path (kMaxSplits slabs)
+        RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y), (size_t)std::max<long long>(t, 8 * std::min<long long>(t, 1152)) * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qkv), (size_t)t * 3 * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ctx), (size_t)t * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ffn), (size_t)t * c.intermediate * sizeof(float)));
@@ -97,6 +99,7 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
     return RAG_OK;
 }
 
+// Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip.
 int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
                 int ldc, int M, int N, int K, int act, hipStream_t st) {
     if (M <= 0) return RAG_OK;
@@ -105,8 +108,49 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldw = ldw; g.ldr = ldr; g.ldc = ldc;
     g.act = act;
-    dim3 grid((N + ragb::GBN - 1) / ragb::GBN, (M + ragb::GBM - 1) / ragb::GBM);
-    ragb::gemm_nt_kernel<<<grid, dim3(256), 0, st>>>(g);
+    g.k_per_split = K;
+    if (M > 1024) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+        ragb::gemm_nt_kernel<2, 2><<<grid, dim3(256), 0, st>>>(g);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
+        ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
+    }
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+// y = LayerNorm(A Wᵀ + bias + R).  Small M: split-K GEMM into partial slabs (`part`, room for
+// kMaxSplits * M * N floats) reduced by the LayerNorm kernel; big M: fused-epilogue GEMM into `part`,
+// then LayerNorm.
+constexpr int kMaxSplits = ragb::kMaxSplitK;
+int launch_gemm_ln(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, float* part,
+                   const float* ln_g, const float* ln_b, float* y, int M, int N, int K, float eps, int n_cus,
+                   hipStream_t st) {
+    if (M <= 0) return RAG_OK;
+    int splits = 1;
+    if (M <= 1024) {
+        const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+        splits = std::max(1, std::min({kMaxSplits, (n_cus + tiles - 1) / tiles, K / (4 * ragb::GBK)}));
+    }
+    if (splits == 1) {
+        int rc = launch_gemm(A, lda, W, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
+        if (rc) return rc;
+        ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, 1, nullptr, nullptr, ln_g, ln_b, y, M, N, eps);
+    } else {
+        ragb::GemmParams g;
+        g.A = A; g.W = W; g.bias = nullptr; g.R = nullptr; g.C = part;
+        g.M = M; g.N = N; g.K = K;
+        g.lda = lda; g.ldw = ldw; g.ldr = 0; g.ldc = N;
+        g.act = ragb::ACT_NONE;
+        const int kt = K / ragb::GBK;
+        g.k_per_split = (kt + splits - 1) / splits * ragb::GBK;
+        splits = (K + g.k_per_split - 1) / g.k_per_split;
+        dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
+        ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
+        RAGC_HIP_TRY(hipGetLastError());
+        ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, splits, bias, R, ln_g, ln_b, y, M, N, eps);
+    }
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -154,18 +198,15 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         else
             attention_kernel<64><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
         RAGC_HIP_TRY(hipGetLastError());
-        // attention output projection + residual, LayerNorm
-        rc = launch_gemm(h->ctx, H, lw[2], H, lw[3], h->x, H, h->y, H, T, H, H, ACT_NONE, st);
+        // attention output projection + residual + LayerNorm (x is both residual and destination:
+        // each token's row is read and written by the same wave of the LayerNorm kernel)
+        rc = launch_gemm_ln(h->ctx, H, lw[2], H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
-        layernorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->y, lw[4], lw[5], h->x, T, H, c.ln_eps);
-        RAGC_HIP_TRY(hipGetLastError());
         // feed-forward: act(x W1ᵀ + b1) W2ᵀ + b2 + residual, LayerNorm
         rc = launch_gemm(h->x, H, lw[6], H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
         if (rc) return rc;
-        rc = launch_gemm(h->ffn, I, lw[8], I, lw[9], h->x, H, h->y, H, T, H, I, ACT_NONE, st);
+        rc = launch_gemm_ln(h->ffn, I, lw[8], I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
-        layernorm_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->y, lw[10], lw[11], h->x, T, H, c.ln_eps);
-        RAGC_HIP_TRY(hipGetLastError());
     }
 
     switch (out_kind) {
@@ -216,7 +257,7 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     *out = nullptr;
     if (!cfg || !weights_dev) return ragc_fail(RAG_ERR_INVALID_ARG, "null config or weight table");
     const rag_bert_config& c = *cfg;
-    if (c.hidden <= 0 || c.hidden > 64 * ragb::kMaxPerLane || c.hidden % 32)
+    if (c.hidden <= 0 || c.hidden > 256 * ragb::kMaxChunks || c.hidden % 32)
         return ragc_fail(RAG_ERR_UNSUPPORTED, "hidden=%d (need a multiple of 32, <= 1024)", c.hidden);
     if (c.n_heads <= 0 || c.hidden % c.n_heads || (c.hidden / c.n_heads != 32 && c.hidden / c.n_heads != 64))
         return ragc_fail(RAG_ERR_UNSUPPORTED, "head dim %d (need 32 or 64)", c.n_heads > 0 ? c.hidden / c.n_heads : 0);
@@ -247,6 +288,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
         delete h;
         return ragc_fail(RAG_ERR_HIP, "hipStreamCreate failed");
     }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
     *out = h;
     return RAG_OK;
 }

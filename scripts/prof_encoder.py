@@ -1,0 +1,10 @@
+import sys
+sys.path.insert(0, ".")
+sys.argv = ["x"]
+import numpy as np
+import scripts.bench_stages as bs
+from rag_inference_pipeline_amd import _native
+from rag_inference_pipeline_amd.bert import BertConfig
+rng = np.random.default_rng(1)
+q = rng.integers(8, 21, size=32)
+bs.run("encoder bge-base (32 queries)", BertConfig.bge_base(), q, _native.BERT_OUT_CLS, reps=20)
