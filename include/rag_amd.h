@@ -134,6 +134,15 @@ int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int3
                           const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
                           int64_t* out_ids_dev, void* stream);
 
+/* Same, reading the all-gather's receive buffer in place: shard g's block starts at
+ * packed_dev + g * shard_stride_bytes and holds nq*k int64 ids at offset 0 and nq*k fp32 scores at
+ * scores_offset_bytes (the layout rag_inference_pipeline_amd/sharded.py:pack_layout produces).
+ * Ids must be < 2^32 (the merge ranks on 64-bit (score, id) keys). */
+int rag_merge_topk_packed_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                 const void* packed_dev, int64_t shard_stride_bytes,
+                                 int64_t scores_offset_bytes, float* out_scores_dev, int64_t* out_ids_dev,
+                                 void* stream);
+
 /* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
 
 typedef struct rag_bert rag_bert;

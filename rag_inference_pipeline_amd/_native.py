@@ -117,6 +117,8 @@ def _declare(lib: C.CDLL) -> None:
         "rag_index_max_k": (C.c_int32, [C.c_int32, C.c_int32]),
         "rag_merge_topk_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             vp, vp, vp, vp, vp]),
+        "rag_merge_topk_packed_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                   vp, C.c_int64, C.c_int64, vp, vp, vp]),
         "rag_bert_weight_count": (C.c_int32, [C.POINTER(BertConfigStruct)]),
         "rag_bert_create": (C.c_int, [C.POINTER(BertConfigStruct), C.POINTER(vp), C.c_int32, C.c_int32,
                                       C.POINTER(vp)]),

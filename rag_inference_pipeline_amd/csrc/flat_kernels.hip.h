@@ -8,8 +8,8 @@
 //                        fp32 MFMA (v_mfma_f32_32x32x2_f32 == fmaf chain), threshold filter in
 //                        registers, candidates appended to per-workgroup LDS buffers, buffers
 //                        compacted by a wave-level bitonic sort when one overflows.
-// K2  merge_keys_kernel  per query: top-k of the per-workgroup lists (LDS bitonic sort), final
-//                        pass decodes keys into (score, id).
+// K2  tournament_merge_kernel  per query: top-k of the sorted per-workgroup (or per-shard) lists by a
+//                        k-round workgroup-wide max tournament; decodes keys into (score, id).
 // plus small helpers (row norms, query norms, synthetic corpus, neutral fill).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,8 +33,6 @@ typedef unsigned long long u64;
 constexpr int kQT = 32;        // queries per scan pass (MFMA N)
 constexpr int kTileRows = 32;  // corpus rows per wave tile (MFMA M)
 constexpr int kMaxScanWaves = 16;
-constexpr int kMergeThreads = 256;
-constexpr int kMergeMaxKeys = 4096;  // keys sorted per merge workgroup (32 KiB LDS)
 
 // ---- ranking keys -------------------------------------------------------------------------
 
@@ -362,104 +360,107 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 }
 
 // ---- K2: merge ------------------------------------------------------------------------------
+// Top-k of n_lists lists that are each sorted best-first (the per-workgroup lists K1 emits, or the
+// per-shard lists after the all-gather).  One 256-thread workgroup per query plays a k-round
+// tournament: every thread holds the head of the list(s) it owns, a round is one workgroup-wide
+// 64-bit max (shuffles + 4 LDS words), the winner advances its list.  ~150 cycles per round, so
+// k = 10 over 256 lists costs about a microsecond of device time — the bitonic merge this replaces
+// sorted 4096 keys to keep 10 and took 90.
+constexpr int kMergeMaxOwned = 8;  // lists per thread: n_lists <= 2048
 
-struct MergeParams {
-    const u64* in;      // [nq][m_in] keys (0 = empty)
-    u64* out;           // [nq][n_chunks][k] keys (intermediate pass)
-    float* out_scores;  // [nq][k] (final pass)
-    long long* out_ids; // [nq][k] (final pass)
-    const float* qnorm; // [nq] canonical ||q||^2 (L2, final pass)
-    long long id_offset;
-    int m_in;           // keys per query on input
-    int chunk;          // keys per workgroup (<= kMergeMaxKeys)
-    int p2;             // power of two >= chunk
-    int k;
-    int final_pass;     // decode keys into scores / ids
-    int metric;         // 0 IP, 1 L2
-    int out_stride;     // row stride of out_scores / out_ids (elements)
+struct KeyListSrc {  // lists of ranking keys: keys[(q * n_lists + l) * k + pos]
+    const u64* keys;
+    int n_lists, k;
+    __device__ __forceinline__ u64 get(int q, int l, int pos) const {
+        return keys[((size_t)q * n_lists + l) * k + pos];
+    }
 };
 
-__global__ __launch_bounds__(kMergeThreads) void merge_keys_kernel(const MergeParams p) {
-    __shared__ u64 sk[kMergeMaxKeys];
-    const int q = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    const u64* src = p.in + (size_t)q * p.m_in + (size_t)c * p.chunk;
-    const int n = min(p.chunk, p.m_in - c * p.chunk);
-    for (int i = tid; i < p.p2; i += kMergeThreads) sk[i] = i < n ? src[i] : 0ull;
-    __syncthreads();
-    for (int size = 2; size <= p.p2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (p.p2 >> 1); t += kMergeThreads) {
-                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
-                const int j = i | stride;
-                const bool up = ((i & size) == 0);
-                const u64 a = sk[i], b = sk[j];
-                const bool swap = up ? (a < b) : (a > b);
-                if (swap) {
-                    sk[i] = b;
-                    sk[j] = a;
-                }
-            }
-            __syncthreads();
-        }
+struct ShardListSrc {  // per-shard (score, id) results: shard l's element (q * k + pos) of two arrays
+    const float* scores;
+    const long long* ids;
+    long long score_stride;  // floats between consecutive shards' score blocks
+    long long id_stride;     // int64s between consecutive shards' id blocks
+    int k, metric;
+    __device__ __forceinline__ u64 get(int q, int l, int pos) const {
+        const size_t e = (size_t)q * k + pos;
+        const long long id = ids[(size_t)l * id_stride + e];
+        if (id < 0) return 0ull;
+        const float s = scores[(size_t)l * score_stride + e];
+        return make_key(metric ? -s : s, (uint32_t)id);  // L2 lists carry ascending distances
     }
-    if (!p.final_pass) {
-        u64* dst = p.out + ((size_t)q * gridDim.x + c) * p.k;
-        for (int i = tid; i < p.k; i += kMergeThreads) dst[i] = i < p.p2 ? sk[i] : 0ull;
-    } else {
-        for (int i = tid; i < p.k; i += kMergeThreads) {
-            const u64 key = i < p.p2 ? sk[i] : 0ull;
+};
+
+struct MergeOut {
+    float* scores;       // [nq][k]
+    long long* ids;      // [nq][k]
+    const float* qnorm;  // canonical ||q||^2 (index-side L2 only)
+    long long id_offset;
+    int metric;          // 0 IP, 1 L2
+    int from_shards;     // keys carry (-distance, id) of already finished results
+};
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = umax64(v, shfl_xor_u64(v, m));
+    return v;
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, const int n_lists, const int k,
+                                                               const MergeOut out) {
+    __shared__ u64 wmax[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    u64 head[kMergeMaxOwned], next[kMergeMaxOwned];
+    int pos[kMergeMaxOwned];
+#pragma unroll
+    for (int j = 0; j < kMergeMaxOwned; ++j) {
+        const int l = tid + 256 * j;
+        pos[j] = 0;
+        head[j] = (l < n_lists && k > 0) ? src.get(q, l, 0) : 0ull;
+        next[j] = (l < n_lists && k > 1) ? src.get(q, l, 1) : 0ull;  // one key of look-ahead per list
+    }
+    for (int round = 0; round < k; ++round) {
+        u64 best = head[0];
+#pragma unroll
+        for (int j = 1; j < kMergeMaxOwned; ++j) best = umax64(best, head[j]);
+        const u64 wm = wave_max_u64(best);
+        if ((tid & 63) == 0) wmax[round & 1][tid >> 6] = wm;
+        __syncthreads();  // the other parity is free again: its readers passed this barrier's predecessor
+        const u64 bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]),
+                              umax64(wmax[round & 1][2], wmax[round & 1][3]));
+        if (tid == 0) {
             float s;
             long long id;
-            if (key == 0ull) {
-                s = p.metric ? 3.402823466e+38f : -3.402823466e+38f;
+            if (bm == 0ull) {
+                s = out.metric ? 3.402823466e+38f : -3.402823466e+38f;
                 id = -1;
             } else {
-                const float rs = unord32((uint32_t)(key >> 32));
-                if (p.metric) {
-                    const float dist = p.qnorm[q] - rs;
+                const float rs = unord32((uint32_t)(bm >> 32));
+                if (out.from_shards) {
+                    s = out.metric ? -rs : rs;
+                } else if (out.metric) {
+                    const float dist = out.qnorm[q] - rs;
                     s = dist < 0.f ? 0.f : dist;
                 } else {
                     s = rs;
                 }
-                id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + p.id_offset;
+                id = (long long)(0xFFFFFFFFu - (uint32_t)(bm & 0xFFFFFFFFull)) + out.id_offset;
             }
-            p.out_scores[(size_t)q * p.out_stride + i] = s;
-            p.out_ids[(size_t)q * p.out_stride + i] = id;
+            out.scores[(size_t)q * k + round] = s;
+            out.ids[(size_t)q * k + round] = id;
         }
-    }
-}
-
-// Encode sorted (score, id) shard lists into keys for merge_keys_kernel (multi-GPU merge).
-// Ids must be < 2^32 after subtracting id_base (callers pass the smallest id as id_base).
-__global__ void encode_lists_kernel(const float* scores, const long long* ids, u64* keys, int n_shards,
-                                    int nq, int k, int metric, long long id_base) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = n_shards * nq * k;
-    if (i >= total) return;
-    const int j = i % k, q = (i / k) % nq, g = i / (k * nq);
-    const long long id = ids[i];
-    u64 key = 0ull;
-    if (id >= 0) {
-        const float s = scores[i];
-        // L2 lists carry distances (ascending): rank by the negated distance
-        key = make_key(metric ? -s : s, (uint32_t)(id - id_base));
-    }
-    keys[((size_t)q * n_shards + g) * k + j] = key;
-}
-
-// Final pass for the multi-GPU merge: keys (as encoded above) -> (score, id).
-__global__ void decode_lists_kernel(const u64* keys, float* out_scores, long long* out_ids, int total,
-                                    int metric, long long id_base) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const u64 key = keys[i];
-    if (key == 0ull) {
-        out_scores[i] = metric ? 3.402823466e+38f : -3.402823466e+38f;
-        out_ids[i] = -1;
-    } else {
-        const float rs = unord32((uint32_t)(key >> 32));
-        out_scores[i] = metric ? -rs : rs;
-        out_ids[i] = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + id_base;
+        if (bm != 0ull && best == bm) {  // keys are unique, so exactly one thread advances one list
+#pragma unroll
+            for (int j = 0; j < kMergeMaxOwned; ++j) {
+                if (head[j] == bm) {
+                    const int l = tid + 256 * j;
+                    pos[j] += 1;
+                    head[j] = next[j];
+                    next[j] = pos[j] + 1 < k ? src.get(q, l, pos[j] + 1) : 0ull;
+                }
+            }
+        }
     }
 }
 

@@ -146,7 +146,6 @@ struct rag_index {
     float* q_dev = nullptr;  size_t q_dev_cap = 0;          // queries staged from the host
     float* qnorm = nullptr;                                  // kQT floats
     ragk::u64* partial = nullptr; size_t partial_cap = 0;   // kQT * grid * k keys
-    ragk::u64* merge_a = nullptr; ragk::u64* merge_b = nullptr; size_t merge_cap = 0;
     float* out_s_dev = nullptr; long long* out_i_dev = nullptr; size_t out_cap = 0;
     // pinned host staging
     float* q_pin = nullptr; size_t q_pin_cap = 0;
@@ -214,19 +213,6 @@ int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
         int rc = dev_alloc(&h->partial, part);
         if (rc) return rc;
         h->partial_cap = part;
-    }
-    // merge ping-pong: after the first pass at most ceil(grid*k / chunk) * k keys per query
-    const size_t mer = (size_t)ragk::kQT * (((size_t)grid * k + ragk::kMergeMaxKeys - 1) / ragk::kMergeMaxKeys + 2) * 2 * k;
-    if (mer > h->merge_cap) {
-        if (h->merge_a) (void)hipFree(h->merge_a);
-        if (h->merge_b) (void)hipFree(h->merge_b);
-        h->merge_a = h->merge_b = nullptr;
-        h->merge_cap = 0;
-        int rc = dev_alloc(&h->merge_a, mer);
-        if (rc) return rc;
-        rc = dev_alloc(&h->merge_b, mer);
-        if (rc) return rc;
-        h->merge_cap = mer;
     }
     if (!h->qnorm) {
         int rc = dev_alloc(&h->qnorm, (size_t)ragk::kQT);
@@ -299,35 +285,12 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
         h->prof_events.emplace_back(e0, e1);
     }
 
-    // merge passes: [q][m] keys -> [q][k]
-    const u64* in = h->partial;
-    int m = grid * k;
-    u64* bufs[2] = {h->merge_a, h->merge_b};
-    int which = 0;
-    for (;;) {
-        const int chunk = std::min(m, kMergeMaxKeys / k * k);  // whole lists per chunk
-        const int n_chunks = (m + chunk - 1) / chunk;
-        MergeParams mp;
-        mp.in = in;
-        mp.out = bufs[which];
-        mp.out_scores = out_s;
-        mp.out_ids = out_i;
-        mp.qnorm = h->qnorm;
-        mp.id_offset = h->id_offset;
-        mp.m_in = m;
-        mp.chunk = chunk;
-        mp.p2 = next_pow2(chunk);
-        mp.k = k;
-        mp.final_pass = n_chunks == 1;
-        mp.metric = h->metric;
-        mp.out_stride = k;
-        merge_keys_kernel<<<dim3(n_chunks, nq), dim3(kMergeThreads), 0, st>>>(mp);
-        HIP_TRY(hipGetLastError());
-        if (n_chunks == 1) break;
-        in = bufs[which];
-        m = n_chunks * k;
-        which ^= 1;
-    }
+    // merge: per query the top-k of the grid sorted lists, decoded into (score, id)
+    if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
+    KeyListSrc src{h->partial, grid, k};
+    MergeOut mo{out_s, out_i, h->qnorm, h->id_offset, h->metric, 0};
+    tournament_merge_kernel<KeyListSrc><<<dim3(nq), dim3(256), 0, st>>>(src, grid, k, mo);
+    HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
 
@@ -427,7 +390,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
-        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->partial, h->merge_a, h->merge_b, h->out_s_dev, h->out_i_dev};
+        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->partial, h->out_s_dev, h->out_i_dev};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
@@ -655,58 +618,44 @@ extern "C" int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* s
 
 // ---- shard merge ----------------------------------------------------------------------------------
 
-extern "C" int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
-                                     const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
-                                     int64_t* out_ids_dev, void* stream) {
+namespace {
+int merge_shards(int device, int metric, int n_shards, int nq, int k, const float* scores, long long score_stride,
+                 const long long* ids, long long id_stride, float* out_s, long long* out_i, void* stream) {
     using namespace ragk;
-    if (n_shards <= 0 || nq < 0 || k <= 0 || !scores_dev || !ids_dev || !out_scores_dev || !out_ids_dev)
+    if (n_shards <= 0 || nq < 0 || k <= 0 || !scores || !ids || !out_s || !out_i)
         return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (metric != RAG_METRIC_INNER_PRODUCT && metric != RAG_METRIC_L2)
         return fail(RAG_ERR_INVALID_ARG, "unknown metric %d", metric);
-    if (k > kMergeMaxKeys / 2) return fail(RAG_ERR_UNSUPPORTED, "k=%d too large for the merge kernel", k);
+    if (n_shards > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "more than %d shards", 256 * kMergeMaxOwned);
     const int ndev = rag_device_count();
     if (ndev <= 0) return fail(RAG_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(RAG_ERR_NO_DEVICE, "device %d out of range", device);
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
-    hipStream_t st = (hipStream_t)stream;
-    const int total_in = n_shards * nq * k;
-    int m = n_shards * k;
-    const size_t ws_keys = (size_t)nq * m * 2 + (size_t)nq * k;
-    u64* ws = nullptr;
-    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&ws), ws_keys * sizeof(u64), st));
-    u64* bufs[2] = {ws, ws + (size_t)nq * m};
-    u64* fin = ws + (size_t)nq * m * 2;
-    encode_lists_kernel<<<dim3((total_in + 255) / 256), dim3(256), 0, st>>>(scores_dev, reinterpret_cast<const long long*>(ids_dev),
-                                                                           bufs[0], n_shards, nq, k, metric, 0);
-    int which = 0;
-    for (;;) {
-        const int chunk = std::min(m, kMergeMaxKeys / k * k);
-        const int n_chunks = (m + chunk - 1) / chunk;
-        MergeParams mp;
-        mp.in = bufs[which];
-        mp.out = n_chunks == 1 ? fin : bufs[which ^ 1];
-        mp.out_scores = nullptr;
-        mp.out_ids = nullptr;
-        mp.qnorm = nullptr;
-        mp.id_offset = 0;
-        mp.m_in = m;
-        mp.chunk = chunk;
-        mp.p2 = next_pow2(chunk);
-        mp.k = k;
-        mp.final_pass = 0;
-        mp.metric = metric;
-        mp.out_stride = k;
-        merge_keys_kernel<<<dim3(n_chunks, nq), dim3(kMergeThreads), 0, st>>>(mp);
-        if (n_chunks == 1) break;
-        m = n_chunks * k;
-        which ^= 1;
-    }
-    const int total_out = nq * k;
-    decode_lists_kernel<<<dim3((total_out + 255) / 256), dim3(256), 0, st>>>(fin, out_scores_dev,
-                                                                            reinterpret_cast<long long*>(out_ids_dev), total_out, metric, 0);
-    hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(ws, st);
-    if (e != hipSuccess) return fail(RAG_ERR_HIP, "merge launch failed: %s", hipGetErrorString(e));
+    ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
+    MergeOut mo{out_s, out_i, nullptr, 0, metric, 1};
+    tournament_merge_kernel<ShardListSrc><<<dim3(nq), dim3(256), 0, (hipStream_t)stream>>>(src, n_shards, k, mo);
+    HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_merge_topk_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                     const float* scores_dev, const int64_t* ids_dev, float* out_scores_dev,
+                                     int64_t* out_ids_dev, void* stream) {
+    return merge_shards(device, metric, n_shards, nq, k, scores_dev, (long long)nq * k,
+                        reinterpret_cast<const long long*>(ids_dev), (long long)nq * k, out_scores_dev,
+                        reinterpret_cast<long long*>(out_ids_dev), stream);
+}
+
+extern "C" int rag_merge_topk_packed_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                            const void* packed_dev, int64_t shard_stride_bytes,
+                                            int64_t scores_offset_bytes, float* out_scores_dev, int64_t* out_ids_dev,
+                                            void* stream) {
+    if (!packed_dev || shard_stride_bytes % 8 || scores_offset_bytes % 4 || shard_stride_bytes <= 0)
+        return fail(RAG_ERR_INVALID_ARG, "packed layout must keep ids 8-byte and scores 4-byte aligned");
+    const char* base = static_cast<const char*>(packed_dev);
+    return merge_shards(device, metric, n_shards, nq, k, reinterpret_cast<const float*>(base + scores_offset_bytes),
+                        shard_stride_bytes / 4, reinterpret_cast<const long long*>(base), shard_stride_bytes / 8,
+                        out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), stream);
 }

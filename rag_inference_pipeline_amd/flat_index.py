@@ -120,3 +120,12 @@ def merge_topk_device(device: int, metric: int, n_shards: int, nq: int, k: int, 
     _native.check(_native.lib().rag_merge_topk_device(
         int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(scores_ptr),
         C.c_void_p(ids_ptr), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
+
+
+def merge_topk_packed_device(device: int, metric: int, n_shards: int, nq: int, k: int, packed_ptr: int,
+                             shard_stride_bytes: int, scores_offset_bytes: int, out_scores_ptr: int,
+                             out_ids_ptr: int, stream: int = 0) -> None:
+    """Merge straight out of the all-gather receive buffer (rag_merge_topk_packed_device)."""
+    _native.check(_native.lib().rag_merge_topk_packed_device(
+        int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(packed_ptr), int(shard_stride_bytes),
+        int(scores_offset_bytes), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr), C.c_void_p(stream)))

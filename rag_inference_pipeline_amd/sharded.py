@@ -5,8 +5,9 @@ shards naturally — the top-k of a union is the top-k of the per-part top-k lis
 G-rank group owns the contiguous rows [N*r/G, N*(r+1)/G), reports GLOBAL ids (local row + base),
 and a search is:
 
-    local scan + top-k   ->   ONE all_gather of [scores | ids] (12 * nq * k bytes per rank)
-                         ->   merge of G sorted lists on every rank (device kernel)
+    local scan + top-k   ->   ONE all_gather of [ids | scores] (12 * nq * k bytes per rank)
+                         ->   merge of G sorted lists on every rank (one device kernel that
+                              reads the gather's receive buffer in place)
 
 Over xGMI the gather is latency-bound (3.84 KB per rank at nq=32, k=10), so the packed buffer goes
 out as a single collective rather than one per tensor.  `torch.distributed` supplies the group
@@ -27,8 +28,11 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 def pack_layout(nq: int, k: int) -> tuple[int, int]:
-    """(byte offset of the id block, total bytes) of one rank's packed result buffer."""
-    return nq * k * 4, nq * k * 12
+    """(byte offset of the score block, bytes per rank) of one rank's packed result buffer:
+    nq*k int64 ids, then nq*k fp32 scores, padded to a multiple of 8 bytes so that every rank's id
+    block stays 8-byte aligned in the gathered buffer."""
+    n = nq * k
+    return 8 * n, (12 * n + 7) // 8 * 8
 
 
 class _LocalIndex(Protocol):
@@ -71,15 +75,13 @@ class ShardedFlatIndex:
         b = self._bufs.get(key)
         if b is None:
             torch = self._torch
-            ids_off, nbytes = pack_layout(nq, k)
-            pack = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            s_off, nbytes = pack_layout(nq, k)
+            pack = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
             b = {
                 "pack": pack,
-                "pack_s": pack[:ids_off].view(torch.float32).view(nq, k),
-                "pack_i": pack[ids_off:].view(torch.int64).view(nq, k),
+                "pack_i": pack[:s_off].view(torch.int64).view(nq, k),
+                "pack_s": pack[s_off:s_off + 4 * nq * k].view(torch.float32).view(nq, k),
                 "gathered": torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device),
-                "all_s": torch.empty((self.world, nq, k), dtype=torch.float32, device=self.device),
-                "all_i": torch.empty((self.world, nq, k), dtype=torch.int64, device=self.device),
                 "out_s": torch.empty((nq, k), dtype=torch.float32, device=self.device),
                 "out_i": torch.empty((nq, k), dtype=torch.int64, device=self.device),
             }
@@ -110,17 +112,17 @@ class ShardedFlatIndex:
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
         self.local.search_device(queries.data_ptr(), nq, k, b["pack_s"].data_ptr(), b["pack_i"].data_ptr(), stream)
         self._all_gather(b)
-        ids_off, nbytes = pack_layout(nq, k)
-        g = b["gathered"].view(self.world, nbytes)
-        b["all_s"].copy_(g[:, :ids_off].contiguous().view(torch.float32).view(self.world, nq, k))
-        b["all_i"].copy_(g[:, ids_off:].contiguous().view(torch.int64).view(self.world, nq, k))
-        if self._merge is not None:
-            self._merge(self.metric, b["all_s"], b["all_i"], b["out_s"], b["out_i"])
+        s_off, nbytes = pack_layout(nq, k)
+        if self._merge is not None:  # test double: unpack on the host side of the tensor API
+            g = b["gathered"].view(self.world, nbytes)
+            all_i = g[:, :s_off].contiguous().view(torch.int64).view(self.world, nq, k)
+            all_s = g[:, s_off:s_off + 4 * nq * k].contiguous().view(torch.float32).view(self.world, nq, k)
+            self._merge(self.metric, all_s, all_i, b["out_s"], b["out_i"])
         else:
-            from .flat_index import merge_topk_device
+            from .flat_index import merge_topk_packed_device
 
-            merge_topk_device(self.device.index or 0, self.metric, self.world, nq, k, b["all_s"].data_ptr(),
-                              b["all_i"].data_ptr(), b["out_s"].data_ptr(), b["out_i"].data_ptr(), stream)
+            merge_topk_packed_device(self.device.index or 0, self.metric, self.world, nq, k, b["gathered"].data_ptr(),
+                                     nbytes, s_off, b["out_s"].data_ptr(), b["out_i"].data_ptr(), stream)
         return b["out_s"], b["out_i"]
 
     def search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:

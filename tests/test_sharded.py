@@ -57,7 +57,8 @@ def test_shard_ranges_partition_the_corpus():
         assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
         sizes = [hi - lo for lo, hi in edges]
         assert max(sizes) - min(sizes) <= 1
-    assert pack_layout(32, 10) == (1280, 3840)  # 3.84 KB per rank per batch
+    assert pack_layout(32, 10) == (2560, 3840)  # 3.84 KB per rank per batch
+    assert pack_layout(1, 1) == (8, 16) and pack_layout(3, 5)[1] % 8 == 0
 
 
 @pytest.mark.parametrize("world,metric", [(2, 0), (3, 1)])
