@@ -162,8 +162,9 @@ struct GemmParams {
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ __attribute__((aligned(16))) float As[BM * GLD];
-    __shared__ __attribute__((aligned(16))) float Ws[BN * GLD];
+    constexpr int NBUF = (TM * TN == 1) ? 2 : 1;  // small tiles double-buffer LDS: one barrier per K-tile
+    __shared__ __attribute__((aligned(16))) float As_[NBUF][BM * GLD];
+    __shared__ __attribute__((aligned(16))) float Ws_[NBUF][BN * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -210,15 +211,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
             for (int j = 0; j < 2 * TN; ++j) rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)kt * GBK);
         }
     };
-    auto stage_tile = [&](const f32x4 (&ra)[2 * TM], const f32x4 (&rw)[2 * TN]) {
-        __syncthreads();  // previous tile fully consumed
+    auto write_tile = [&](const f32x4 (&ra)[2 * TM], const f32x4 (&rw)[2 * TN], int buf) {
+        float* As = As_[buf];
+        float* Ws = Ws_[buf];
 #pragma unroll
         for (int j = 0; j < 2 * TM; ++j) *reinterpret_cast<f32x4*>(&As[(srow + 32 * j) * GLD + scol]) = ra[j];
 #pragma unroll
         for (int j = 0; j < 2 * TN; ++j) *reinterpret_cast<f32x4*>(&Ws[(srow + 32 * j) * GLD + scol]) = rw[j];
-        __syncthreads();
     };
-    auto multiply_tile = [&]() {
+    auto multiply_tile = [&](int buf) {
+        const float* As = As_[buf];
+        const float* Ws = Ws_[buf];
 #pragma unroll
         for (int kg = 0; kg < GBK / 8; ++kg) {
             f32x4 af[TM], bf[TN];
@@ -238,26 +241,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
         }
     };
     if constexpr (TM * TN == 1) {
+        // LDS double-buffered, registers one more tile ahead: per K-tile {multiply buf, write the next
+        // tile into the other buffer, fetch the tile after that, ONE barrier}.
         load_tile(ra0, rw0, 0);
         load_tile(ra1, rw1, 1);
+        write_tile(ra0, rw0, 0);
+        load_tile(ra0, rw0, 2);
+        __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
-            stage_tile(ra0, rw0);
-            load_tile(ra0, rw0, kt + 2);
-            multiply_tile();
+            multiply_tile(0);
             if (kt + 1 < nk) {  // block-uniform
-                stage_tile(ra1, rw1);
+                write_tile(ra1, rw1, 1);
                 load_tile(ra1, rw1, kt + 3);
-                multiply_tile();
+            }
+            __syncthreads();
+            if (kt + 1 < nk) {
+                multiply_tile(1);
+                if (kt + 2 < nk) {
+                    write_tile(ra0, rw0, 0);
+                    load_tile(ra0, rw0, kt + 4);
+                }
+                __syncthreads();
             }
         }
     } else {
-        // big tiles: 64 MFMAs per wave per K-tile and 2-3 workgroups per CU already cover the loads;
-        // the second register set only costs occupancy (measured: 203 VGPRs, 0.65x the throughput)
+        // big tiles: single LDS buffer, one register set, two barriers per K-tile.  64 MFMAs per wave per
+        // tile and 3 workgroups per CU already hide the staging; measured alternatives were slower —
+        // a second register set (203 VGPRs) 0.65x, a second LDS buffer (74 KB, 2 workgroups/CU) 0.9x.
         load_tile(ra0, rw0, 0);
         for (int kt = 0; kt < nk; ++kt) {
-            stage_tile(ra0, rw0);
+            __syncthreads();  // previous tile fully consumed
+            write_tile(ra0, rw0, 0);
+            __syncthreads();
             load_tile(ra0, rw0, kt + 1);
-            multiply_tile();
+            multiply_tile(0);
         }
     }
 
