@@ -98,6 +98,12 @@ struct ScanParams {
     const float* xnorm;    // canonical squared norms (L2 metric only)
     const float* Q;        // queries, row-major nq x d (un-padded)
     u64* partial;          // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
+    const u64* ceil;       // [kQT] or null: only keys strictly below ceil[q] are candidates (k > max_k rounds)
+    float* acc_io;         // [n_tiles*32][kQT] running inner products (d > 1024 is scanned in column chunks)
+    int col0;              // first column of this launch's chunk (multiple of 8)
+    int dc8;               // columns in this chunk, multiple of 8 (== d8 when the scan is not chunked)
+    int acc_in;            // start from acc_io instead of zero
+    int acc_out;           // store the accumulators to acc_io and skip the selection
     long long n_rows;
     long long row_stride;
     int d;                 // logical dimension
@@ -109,7 +115,7 @@ struct ScanParams {
 };
 
 // LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32]
-__host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {
+__host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = columns held in LDS (one chunk)
     return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16;
 }
 
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r = lane & 31;
-    const int S = p.d8 >> 3;
+    const int S = p.dc8 >> 3;
 
     f32x4* qf = reinterpret_cast<f32x4*>(smem);
     u64* keys = reinterpret_cast<u64*>(smem + (size_t)S * 1024);
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
     for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
         const int s = idx >> 6, l = idx & 63;
-        const int qrow = l & 31, col = 8 * s + 4 * (l >> 5);
+        const int qrow = l & 31, col = p.col0 + 8 * s + 4 * (l >> 5);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (qrow < p.nq) {
             const float* src = p.Q + (size_t)qrow * p.d + col;
@@ -161,9 +167,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 #endif
         long long row = (long long)t * kTileRows + r;
         row = row < last_row ? row : last_row;
-        return p.X + row * p.row_stride + 4 * h;
+        return p.X + row * p.row_stride + p.col0 + 4 * h;
     };
 
+    const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
     f32x4 xb[D];
     const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
 #pragma unroll
@@ -182,6 +189,11 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (p.acc_in && active) {  // continue the fmaf chains of the previous column chunk
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                acc[i] = p.acc_io[((size_t)tile * kTileRows + (i & 3) + 8 * (i >> 2) + 4 * h) * kQT + r];
+        }
 
         // One step = 8 columns = 4 MFMAs on ring slot i.  The ring is refilled G slots at a time,
         // D steps ahead: with G = 4 the four loads that make up one 128-byte line of each of the
@@ -241,6 +253,15 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         }
         pc = pn;
 
+        if (p.acc_out) {  // not the last column chunk: park the partial sums (kernel-uniform branch)
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    p.acc_io[((size_t)tile * kTileRows + (i & 3) + 8 * (i >> 2) + 4 * h) * kQT + r] = acc[i];
+            }
+            continue;
+        }
+
         // ---- ranking scores.  Lane (r, h): query r, tile rows (i&3) + 8(i>>2) + 4h.
         const long long row0 = (long long)tile * kTileRows;
         float sc[16];
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (sc[i] >= t && row <= last_row) {
+                    if (sc[i] >= t && row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil) {
                         const uint32_t slot = atomicAdd(&cnt[r], 1u);
                         if (slot < (uint32_t)C) {
                             keys[(size_t)r * C + slot] = make_key(sc[i], (uint32_t)row);
@@ -340,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         }
     }
 
+    if (p.acc_out) return;
     // ---- epilogue: sort every buffer, emit k keys per query for this workgroup
     for (int q = wave; q < kQT; q += kScanWaves) {
         const uint32_t n = min(cnt[q], (uint32_t)C);
@@ -392,8 +414,10 @@ struct ShardListSrc {  // per-shard (score, id) results: shard l's element (q * 
 };
 
 struct MergeOut {
-    float* scores;       // [nq][k]
-    long long* ids;      // [nq][k]
+    float* scores;       // [nq][out_stride], this call fills columns 0..k-1
+    long long* ids;      // [nq][out_stride]
+    u64* last_key;       // [nq] or null: the k-th key of this call (0 if the lists ran dry)
+    int out_stride;
     const float* qnorm;  // canonical ||q||^2 (index-side L2 only)
     long long id_offset;
     int metric;          // 0 IP, 1 L2
@@ -447,8 +471,9 @@ __global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, co
                 }
                 id = (long long)(0xFFFFFFFFu - (uint32_t)(bm & 0xFFFFFFFFull)) + out.id_offset;
             }
-            out.scores[(size_t)q * k + round] = s;
-            out.ids[(size_t)q * k + round] = id;
+            out.scores[(size_t)q * out.out_stride + round] = s;
+            out.ids[(size_t)q * out.out_stride + round] = id;
+            if (out.last_key && round == k - 1) out.last_key[q] = bm;
         }
         if (bm != 0ull && best == bm) {  // keys are unique, so exactly one thread advances one list
 #pragma unroll

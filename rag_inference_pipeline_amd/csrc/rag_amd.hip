@@ -70,6 +70,11 @@ int pick_capacity(int d8, int k) {
     return 0;
 }
 
+// Column chunk held in LDS per launch: the whole row up to 1024 columns, else 768 (so k up to 112 fits
+// beside the query image); the last chunk takes the remainder.
+constexpr int kChunkCols = 768;
+int chunk_cols(int d8) { return d8 <= 1024 ? d8 : kChunkCols; }
+
 int pick_ring(int S) {
     for (int dpt : {8, 4, 2})
         if (S % dpt == 0 && S >= dpt) return dpt;
@@ -145,6 +150,8 @@ struct rag_index {
     // per-search workspace (grown on demand, device memory)
     float* q_dev = nullptr;  size_t q_dev_cap = 0;          // queries staged from the host
     float* qnorm = nullptr;                                  // kQT floats
+    ragk::u64* round_keys = nullptr;                         // 2 x kQT keys (k > max_k rounds)
+    float* acc_io = nullptr; long long acc_rows = 0;         // running sums when d > 1024 is scanned in chunks
     ragk::u64* partial = nullptr; size_t partial_cap = 0;   // kQT * grid * k keys
     float* out_s_dev = nullptr; long long* out_i_dev = nullptr; size_t out_cap = 0;
     // pinned host staging
@@ -191,6 +198,10 @@ int grow_rows(rag_index* h, long long want) {
     h->X = nx;
     h->xnorm = nn;
     h->cap_rows = cap;
+    if (h->acc_io) {  // sized by capacity: reallocated by the next chunked search
+        (void)hipFree(h->acc_io);
+        h->acc_io = nullptr;
+    }
     return RAG_OK;
 }
 
@@ -223,23 +234,17 @@ int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
 }
 
 // One pass of <= 32 queries: scan + merge into out (device pointers, row stride k).
-int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i, hipStream_t st) {
+// `ceil` (device, kQT keys, or null) restricts candidates to keys below it; `last_key` (device, kQT keys, or
+// null) receives each query's k-th key; results go to columns [0, k) of rows of `out_stride` elements.
+int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u64* ceil, ragk::u64* last_key,
+                 float* out_s, long long* out_i, int out_stride, hipStream_t st) {
     using namespace ragk;
-    const int cap = pick_capacity(h->d8, k);
+    const int dc_full = chunk_cols(h->d8);
+    const int cap = pick_capacity(dc_full, k);
     if (cap == 0)
         return fail(RAG_ERR_UNSUPPORTED, "k=%d with d=%d exceeds the fused scan kernel's LDS budget (max k %d)", k, h->d,
                     rag_index_max_k(h->d, nq));
-    const int S = h->d8 / 8;
-    int ring = pick_ring(S);
     int waves = 8;
-#ifdef RAGK_TUNING
-    {   // tuning overrides (scripts/tune_scan.py builds a side library with -DRAGK_TUNING)
-        const int w = env_int("RAG_AMD_SCAN_WAVES", 0);
-        if (w == 8 || w == 12 || w == 16) waves = w;
-        const int rg = env_int("RAG_AMD_SCAN_RING", 0);
-        if (ring_ok(S, rg)) ring = rg;
-    }
-#endif
     const bool l2 = h->metric == RAG_METRIC_L2;
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
     const int n_tiles = (int)n_tiles_ll;
@@ -249,28 +254,17 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
 
     int rc = ensure_search_ws(h, nq, k, grid);
     if (rc) return rc;
+    const bool chunked = h->d8 > dc_full;
+    if (chunked && !h->acc_io) {
+        rc = dev_alloc(&h->acc_io, (size_t)((h->cap_rows + 31) / 32 * 32) * kQT);
+        if (rc) return rc;
+        h->acc_rows = h->cap_rows;
+    }
 
     if (l2) {
         row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(q_dev, h->d, h->d, 0, nq, h->qnorm);
         HIP_TRY(hipGetLastError());
     }
-
-    ScanParams sp;
-    sp.X = h->X;
-    sp.xnorm = h->xnorm;
-    sp.Q = q_dev;
-    sp.partial = h->partial;
-    sp.n_rows = h->n;
-    sp.row_stride = h->d8;
-    sp.d = h->d;
-    sp.d8 = h->d8;
-    sp.nq = nq;
-    sp.k = k;
-    sp.n_tiles = n_tiles;
-    sp.n_iters = n_iters;
-    ScanFn fn = scan_fn(waves, cap, ring, l2);
-    const size_t lds = scan_lds_bytes(h->d8, cap);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
@@ -278,8 +272,43 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
-    HIP_TRY(hipGetLastError());
+    for (int col0 = 0; col0 < h->d8; col0 += dc_full) {
+        const int dc8 = std::min(dc_full, h->d8 - col0);
+        const int S = dc8 / 8;
+        int ring = pick_ring(S);
+#ifdef RAGK_TUNING
+        {   // tuning overrides (scripts/tune_scan.py builds a side library with -DRAGK_TUNING)
+            const int w = env_int("RAG_AMD_SCAN_WAVES", 0);
+            if (w == 8 || w == 12 || w == 16) waves = w;
+            const int rg = env_int("RAG_AMD_SCAN_RING", 0);
+            if (ring_ok(S, rg)) ring = rg;
+        }
+#endif
+        ScanParams sp;
+        sp.X = h->X;
+        sp.xnorm = h->xnorm;
+        sp.Q = q_dev;
+        sp.partial = h->partial;
+        sp.ceil = ceil;
+        sp.acc_io = h->acc_io;
+        sp.col0 = col0;
+        sp.dc8 = dc8;
+        sp.acc_in = col0 > 0;
+        sp.acc_out = col0 + dc8 < h->d8;
+        sp.n_rows = h->n;
+        sp.row_stride = h->d8;
+        sp.d = h->d;
+        sp.d8 = h->d8;
+        sp.nq = nq;
+        sp.k = k;
+        sp.n_tiles = n_tiles;
+        sp.n_iters = n_iters;
+        ScanFn fn = scan_fn(waves, cap, ring, l2);
+        const size_t lds = scan_lds_bytes(dc8, cap);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
+        HIP_TRY(hipGetLastError());
+    }
     if (h->prof) {
         HIP_TRY(hipEventRecord(e1, st));
         h->prof_events.emplace_back(e0, e1);
@@ -288,7 +317,7 @@ int search_pass(rag_index* h, const float* q_dev, int nq, int k, float* out_s, l
     // merge: per query the top-k of the grid sorted lists, decoded into (score, id)
     if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
     KeyListSrc src{h->partial, grid, k};
-    MergeOut mo{out_s, out_i, h->qnorm, h->id_offset, h->metric, 0};
+    MergeOut mo{out_s, out_i, last_key, out_stride, h->qnorm, h->id_offset, h->metric, 0};
     tournament_merge_kernel<KeyListSrc><<<dim3(nq), dim3(256), 0, st>>>(src, grid, k, mo);
     HIP_TRY(hipGetLastError());
     return RAG_OK;
@@ -313,10 +342,34 @@ int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float*
         HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
+    // k beyond what one fused pass can select (LDS budget): take the results in rounds of kmax, each
+    // round a full scan restricted to keys below the previous round's last key.
+    const int kmax = rag_index_max_k(h->d, nq);
+    if (kmax <= 0) return fail(RAG_ERR_UNSUPPORTED, "dimension %d is not supported by the scan kernel", h->d);
+    if (k > kmax && !h->round_keys) {
+        int rc = dev_alloc(&h->round_keys, (size_t)2 * ragk::kQT);
+        if (rc) return rc;
+    }
     for (int q0 = 0; q0 < nq; q0 += ragk::kQT) {
         const int nb = std::min(ragk::kQT, nq - q0);
-        int rc = search_pass(h, q_dev + (size_t)q0 * h->d, nb, k, out_s + (size_t)q0 * k, out_i + (size_t)q0 * k, st);
-        if (rc) return rc;
+        const float* qp = q_dev + (size_t)q0 * h->d;
+        float* os = out_s + (size_t)q0 * k;
+        long long* oi = out_i + (size_t)q0 * k;
+        if (k <= kmax) {
+            int rc = search_round(h, qp, nb, k, nullptr, nullptr, os, oi, k, st);
+            if (rc) return rc;
+            continue;
+        }
+        int done = 0, flip = 0;
+        while (done < k) {
+            const int kr = std::min(kmax, k - done);
+            const ragk::u64* ceil = done ? h->round_keys + (size_t)flip * ragk::kQT : nullptr;
+            ragk::u64* last = h->round_keys + (size_t)(flip ^ 1) * ragk::kQT;
+            int rc = search_round(h, qp, nb, kr, ceil, last, os + done, oi + done, k, st);
+            if (rc) return rc;
+            done += kr;
+            flip ^= 1;
+        }
     }
     return RAG_OK;
 }
@@ -354,8 +407,6 @@ extern "C" int rag_index_create(int32_t d, int32_t metric, int32_t device, rag_i
     if (ndev <= 0) return fail(RAG_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(RAG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
     const int d8 = round_up(d, 8);
-    if (pick_capacity(d8, 1) == 0)
-        return fail(RAG_ERR_UNSUPPORTED, "dimension %d: query fragments (%d KiB) do not fit the 160 KiB LDS", d, d8 / 8);
     DeviceGuard g(device);
     if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
     rag_index* h = new (std::nothrow) rag_index();
@@ -390,7 +441,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
-        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->partial, h->out_s_dev, h->out_i_dev};
+        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
@@ -497,10 +548,10 @@ extern "C" int rag_index_set_id_offset(rag_index* h, int64_t id_offset) {
 extern "C" int32_t rag_index_max_k(int32_t d, int32_t nq) {
     (void)nq;
     if (d <= 0) return 0;
-    const int d8 = round_up(d, 8);
+    const int dc = chunk_cols(round_up(d, 8));
     int best = 0;
     for (int c : {64, 128, 256})
-        if (ragk::scan_lds_bytes(d8, c) <= 160 * 1024) best = c - 16;
+        if (ragk::scan_lds_bytes(dc, c) <= 160 * 1024) best = c - 16;
     return best;
 }
 
@@ -633,7 +684,7 @@ int merge_shards(int device, int metric, int n_shards, int nq, int k, const floa
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
     ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
-    MergeOut mo{out_s, out_i, nullptr, 0, metric, 1};
+    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1};
     tournament_merge_kernel<ShardListSrc><<<dim3(nq), dim3(256), 0, (hipStream_t)stream>>>(src, n_shards, k, mo);
     HIP_TRY(hipGetLastError());
     return RAG_OK;

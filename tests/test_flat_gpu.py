@@ -32,6 +32,12 @@ CASES = [
     (777, 100, 3, 10, 0),         # d not a multiple of 8, ragged N
     (33, 8, 32, 10, 0),
     (70_001, 128, 40, 10, 0),     # nq > 32 -> two passes
+    (9_000, 1536, 32, 10, 0),     # d > 1024 -> two column chunks with parked partial sums
+    (5_000, 1100, 9, 20, 1),      # ragged chunks (768 + 336 padded), L2
+    (3_000, 3072, 32, 100, 0),    # four chunks, k = 100
+    (30_000, 384, 32, 300, 0),    # k > max_k(384) = 240 -> two rounds with a key ceiling
+    (6_000, 768, 5, 250, 1),      # k > max_k(768) = 112 -> three rounds, L2
+    (200, 768, 3, 150, 0),        # rounds run past the end of a tiny corpus (-1 padding)
 ]
 
 

@@ -58,7 +58,7 @@ def test_max_k_reports_lds_budget(lib):
     assert lib.rag_index_max_k(384, 32) == 240
     assert lib.rag_index_max_k(768, 32) == 112
     assert lib.rag_index_max_k(1024, 32) == 48
-    assert lib.rag_index_max_k(4096, 32) == 0
+    assert lib.rag_index_max_k(4096, 32) == 112  # d > 1024 is scanned in 768-column chunks
 
 
 def test_index_file_formats_roundtrip(tmp_path):
