@@ -241,26 +241,28 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
         }
     };
     if constexpr (TM * TN == 1) {
-        // LDS double-buffered, registers one more tile ahead: per K-tile {multiply buf, write the next
-        // tile into the other buffer, fetch the tile after that, ONE barrier}.
+        // LDS double-buffered, registers two tiles ahead: per K-tile {write the tile fetched two tiles ago
+        // into the free buffer, fetch the tile after next into those registers, multiply the current
+        // buffer, ONE barrier}.  The write comes first so that its registers were loaded two multiplies
+        // (not one) earlier — one multiply of 16 MFMAs per wave is shorter than an L2 round trip.
         load_tile(ra0, rw0, 0);
         load_tile(ra1, rw1, 1);
         write_tile(ra0, rw0, 0);
         load_tile(ra0, rw0, 2);
         __syncthreads();
         for (int kt = 0; kt < nk; kt += 2) {
-            multiply_tile(0);
             if (kt + 1 < nk) {  // block-uniform
                 write_tile(ra1, rw1, 1);
                 load_tile(ra1, rw1, kt + 3);
             }
+            multiply_tile(0);
             __syncthreads();
             if (kt + 1 < nk) {
-                multiply_tile(1);
                 if (kt + 2 < nk) {
                     write_tile(ra0, rw0, 0);
                     load_tile(ra0, rw0, kt + 4);
                 }
+                multiply_tile(1);
                 __syncthreads();
             }
         }
@@ -299,6 +301,121 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
                     Cz[(size_t)m * p.ldc + n] = v;
                 }
             }
+        }
+    }
+}
+
+// Small-M GEMM: 64 x 64 x 64 tiles, EIGHT waves.  Waves 0-3 (2 x 2 over the tile) multiply columns 0-31 of
+// every staged K-tile, waves 4-7 columns 32-63, so each SIMD holds two waves whose LDS waits and barrier
+// waits hide behind each other's MFMAs (with one wave per SIMD half of each K-step was exposed latency);
+// the two partial tiles are added through LDS at the end in a fixed order.  Same split-K / epilogue
+// contract as gemm_nt_kernel.  Requires k_per_split % 64 == 0.
+constexpr int SBK = 64, SLD = 68;  // 68 r mod 64 = 4 r: 16 rows of a ds_read_b128 group hit 16 distinct slots
+
+__global__ __launch_bounds__(512) void gemm_nt_small_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As_[2][64 * SLD];
+    __shared__ __attribute__((aligned(16))) float Ws_[2][64 * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const bool split = gridDim.z > 1;
+
+    const int srow = tid >> 4, scol = (tid & 15) * 4;  // 32 rows x 16 float4 per pass, 2 passes
+    const float* ag[2];
+    const float* wg[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int am = m0 + srow + 32 * j;
+        am = am < p.M ? am : p.M - 1;
+        int wr = n0 + srow + 32 * j;
+        wr = wr < p.N ? wr : p.N - 1;
+        ag[j] = p.A + (size_t)am * p.lda + kbeg + scol;
+        wg[j] = p.W + (size_t)wr * p.ldw + kbeg + scol;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int nk = (kend - kbeg) / SBK;
+    f32x4 ra0[2], rw0[2], ra1[2], rw1[2];
+    auto load_tile = [&](f32x4 (&ra)[2], f32x4 (&rw)[2], int kt) {
+        if (kt < nk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)kt * SBK);
+                rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)kt * SBK);
+            }
+        }
+    };
+    auto write_tile = [&](const f32x4 (&ra)[2], const f32x4 (&rw)[2], int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<f32x4*>(&As_[buf][(srow + 32 * j) * SLD + scol]) = ra[j];
+            *reinterpret_cast<f32x4*>(&Ws_[buf][(srow + 32 * j) * SLD + scol]) = rw[j];
+        }
+    };
+    auto multiply_tile = [&](int buf) {
+        const float* As = &As_[buf][(wm * 32 + r) * SLD + kh * 32 + 4 * h];
+        const float* Ws = &Ws_[buf][(wn * 32 + r) * SLD + kh * 32 + 4 * h];
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(As + kg * 8);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(Ws + kg * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[t], acc, 0, 0, 0);
+        }
+    };
+    load_tile(ra0, rw0, 0);
+    load_tile(ra1, rw1, 1);
+    write_tile(ra0, rw0, 0);
+    load_tile(ra0, rw0, 2);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) {  // block-uniform
+            write_tile(ra1, rw1, 1);
+            load_tile(ra1, rw1, kt + 3);
+        }
+        multiply_tile(0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) {
+                write_tile(ra0, rw0, 0);
+                load_tile(ra0, rw0, kt + 4);
+            }
+            multiply_tile(1);
+            __syncthreads();
+        }
+    }
+
+    // add the two K-halves: waves 4-7 park their tile in LDS (the staging buffers are free after the
+    // loop's last barrier), waves 0-3 add it to theirs (low half + high half, always in that order)
+    float* xch = &As_[0][0];  // 4 waves x 16 regs x 64 lanes x 4 B = 16 KB <= sizeof(As_[0])
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xch[((wave & 3) * 16 + i) * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += xch[((wave & 3) * 16 + i) * 64 + lane];
+
+    float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
+    const int n = n0 + wn * 32 + r;
+    if (n >= p.N) return;
+    const float bias = (!split && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (m < p.M) {
+            float v = acc[i];
+            if (!split) {
+                v = apply_act(v + bias, p.act);
+                if (p.R) v += p.R[(size_t)m * p.ldr + n];
+            }
+            Cz[(size_t)m * p.ldc + n] = v;
         }
     }
 }

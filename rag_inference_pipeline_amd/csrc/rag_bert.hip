@@ -114,7 +114,10 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
         ragb::gemm_nt_kernel<2, 2><<<grid, dim3(256), 0, st>>>(g);
     } else {
         dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
-        ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
+        if (K % ragb::SBK == 0)
+            ragb::gemm_nt_small_kernel<<<grid, dim3(512), 0, st>>>(g);
+        else
+            ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
     }
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
@@ -143,11 +146,16 @@ int launch_gemm_ln(const float* A, int lda, const float* W, int ldw, const float
         g.M = M; g.N = N; g.K = K;
         g.lda = lda; g.ldw = ldw; g.ldr = 0; g.ldc = N;
         g.act = ragb::ACT_NONE;
-        const int kt = K / ragb::GBK;
-        g.k_per_split = (kt + splits - 1) / splits * ragb::GBK;
+        const bool small8 = K % ragb::SBK == 0;
+        const int step = small8 ? ragb::SBK : ragb::GBK;
+        const int kt = K / step;
+        g.k_per_split = (kt + splits - 1) / splits * step;
         splits = (K + g.k_per_split - 1) / g.k_per_split;
         dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
-        ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
+        if (small8)
+            ragb::gemm_nt_small_kernel<<<grid, dim3(512), 0, st>>>(g);
+        else
+            ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
         RAGC_HIP_TRY(hipGetLastError());
         ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, splits, bias, R, ln_g, ln_b, y, M, N, eps);
     }
