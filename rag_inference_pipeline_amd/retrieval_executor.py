@@ -14,6 +14,7 @@ and yields one RetrievalResponseItem per request, in request order.  Semantics k
   * without a document store, or in `id_only` mode, documents are id-only stubs (api.py:436-451)
   * scores are zipped onto documents without a length check (api.py:491, strict=False)
   * with a reranker the returned list and scores are the reranker's (api.py:495-514)
+  * unless DISABLE_CACHE_FOR_PROFILING is set, index results are cached per embedding (api.py:392-425)
 What is different: rerank runs as ONE batched call over the whole batch (rerank_batch) instead of
 a thread pool of per-query calls (api.py:579-589) — the GPU cross-encoder batches all pairs.
 The `compressed` payload mode (lz4 of msgspec JSON, api.py:516-523) is wire format and not built.
@@ -22,7 +23,9 @@ The `compressed` payload mode (lz4 of msgspec JSON, api.py:516-523) is wire form
 from __future__ import annotations
 
 import asyncio
+import hashlib
 import logging
+import threading
 import time
 from collections.abc import Sequence
 from typing import Any
@@ -30,6 +33,7 @@ from typing import Any
 import numpy as np
 
 from .batch_scheduler import Batch, BatchScheduler
+from .cache import LRUCache
 from .component_registry import ComponentRegistry
 from .components.document_store import Document as StoreDocument
 from .components.schemas import Document
@@ -60,6 +64,11 @@ class RetrievalExecutor:
             service_name="retrieval",
             enable_adaptive=getattr(self.settings, "enable_adaptive_batching", True),
         )
+        # per-embedding result cache (reference api.py:310-315); bypassed in measurement mode
+        self.cache: LRUCache[str, tuple[list[int], list[float]]] = LRUCache(
+            capacity=self.settings.retrieval_cache_capacity, ttl=self.settings.cache_max_ttl,
+            name="retrieval_faiss_cache")
+        self._lock = threading.Lock()
 
     async def start(self) -> None:
         await self.scheduler.start()
@@ -86,11 +95,39 @@ class RetrievalExecutor:
         with stage_timers.track(STAGE_EMBEDDING):
             return embedder.encode([req.query for req in batch.requests])
 
+    def clear_cache(self) -> None:
+        with self._lock:
+            self.cache.clear()
+
     def _search(self, embeddings: np.ndarray) -> tuple[list[list[int]], list[list[float]]]:
+        """Index search, with the reference's optional result cache keyed by sha256 of the embedding
+        bytes (api.py:376-425): hits skip the index, misses are searched as one smaller batch."""
         index = self.registry.get("faiss_store")
-        with stage_timers.track(STAGE_FAISS_SEARCH):
-            distances, indices = index.search(embeddings, self.settings.retrieval_k)
-        return [row.tolist() for row in indices], [row.tolist() for row in distances]
+        k = self.settings.retrieval_k
+        if getattr(self.settings, "disable_cache_for_profiling", True):
+            with stage_timers.track(STAGE_FAISS_SEARCH):
+                distances, indices = index.search(embeddings, k)
+            return [row.tolist() for row in indices], [row.tolist() for row in distances]
+        n = embeddings.shape[0]
+        ids_out: list[list[int]] = [[] for _ in range(n)]
+        dist_out: list[list[float]] = [[] for _ in range(n)]
+        keys = [hashlib.sha256(embeddings[i].tobytes()).hexdigest() for i in range(n)]
+        missing = []
+        with self._lock:
+            for i, key in enumerate(keys):
+                hit = self.cache.get(key)
+                if hit:
+                    ids_out[i], dist_out[i] = hit
+                else:
+                    missing.append(i)
+        if missing:
+            with stage_timers.track(STAGE_FAISS_SEARCH):
+                distances, indices = index.search(np.array([embeddings[i] for i in missing]), k)
+            with self._lock:
+                for row, i in enumerate(missing):
+                    ids_out[i], dist_out[i] = indices[row].tolist(), distances[row].tolist()
+                    self.cache.put(keys[i], (ids_out[i], dist_out[i]))
+        return ids_out, dist_out
 
     def _fetch_documents(self, doc_ids_batch: list[list[int]]) -> list[list[StoreDocument]]:
         store = self.registry.get("document_store")

@@ -1,22 +1,48 @@
-"""Stage timings of the transformer side (encoder / cross-encoder) with GEMM flop accounting."""
-import sys, time
+"""Stage timings of the transformer side (query encoder / cross-encoder) with GEMM flop accounting
+and the torch-CPU oracle timed beside each stage on a bounded sample.
+
+    python scripts/bench_stages.py [--json profiles/rNN_stages.json] [--no-cpu]
+"""
+import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import torch
 from rag_inference_pipeline_amd import _native
 from rag_inference_pipeline_amd.bert import BertConfig, BertModel, random_weights, pack_sequences
 
+FP32_MFMA_PEAK_TF = 157.3
+
+
 def gemm_flops(cfg, T, nseq, head):
     H, I = cfg.hidden, cfg.intermediate
-    per_tok = 2 * (3 * H * H + H * H + 2 * H * I) * cfg.n_layers
-    return per_tok * T + (2 * H * H * nseq if head else 0)
+    return 2 * (3 * H * H + H * H + 2 * H * I) * cfg.n_layers * T + (2 * H * H * nseq if head else 0)
+
 
 def attn_flops(cfg, lens):
-    return sum(4 * L * L * cfg.hidden for L in lens) * cfg.n_layers
+    return sum(4 * int(L) * int(L) * cfg.hidden for L in lens) * cfg.n_layers
 
-def run(name, cfg, lens, out_kind, reps=10):
+
+def cpu_leg(cfg, w, seqs, out_kind, sample, threads):
+    from oracle import bert as obert
+    torch.set_num_threads(threads)
+    sub = seqs[:sample]
+    fn = (lambda: obert.classify(cfg, w, sub)) if out_kind == _native.BERT_OUT_PROBS else (lambda: obert.embed(cfg, w, sub))
+    fn()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn(); reps += 1
+        el = time.perf_counter() - t0
+        if el > 5.0 or reps >= 20:
+            break
+    return {"value": len(sub) * reps / el, "unit": "sequences/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/bert.py (torch-CPU fp32, padded batch) on the first {len(sub)} of {len(seqs)} sequences, "
+                      f"{reps} reps at {el / reps * 1e3:.1f} ms"}
+
+
+def run(name, cfg, lens, out_kind, reps=10, cpu_sample=0, threads=16):
     cfg.vocab_size = min(cfg.vocab_size, 30522)
-    model = BertModel(cfg, random_weights(cfg, 0))
+    w = random_weights(cfg, 0)
+    model = BertModel(cfg, w)
     rng = np.random.default_rng(0)
     seqs = [rng.integers(5, cfg.vocab_size, size=int(n)).tolist() for n in lens]
     ids, types, cu = pack_sequences(seqs, [[0] * len(s) for s in seqs])
@@ -26,26 +52,48 @@ def run(name, cfg, lens, out_kind, reps=10):
     width = cfg.hidden if out_kind in (_native.BERT_OUT_MEAN, _native.BERT_OUT_CLS) else cfg.n_labels
     out = torch.empty((nseq, width), dtype=torch.float32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+
     def go():
         model.forward_device(ids_t.data_ptr(), types_t.data_ptr() if cfg.type_vocab > 1 else 0, cu_t.data_ptr(), nseq, T, L,
                              out_kind, True, out.data_ptr(), st)
     go(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps): go()
+    for _ in range(reps):
+        go()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     gf = gemm_flops(cfg, T, nseq, cfg.head != "none")
+    res = {"stage": name, "nseq": nseq, "tokens": T, "max_len": L, "ms_per_batch": ms, "gemm_gflop": gf / 1e9,
+           "attention_gflop": attn_flops(cfg, lens) / 1e9, "gemm_tflops_end_to_end": gf / ms / 1e9,
+           "frac_of_fp32_mfma_peak": gf / ms / 1e9 / FP32_MFMA_PEAK_TF, "sequences_per_s": nseq / ms * 1e3, "dtype": "f32"}
     print(f"{name}: nseq={nseq} tokens={T} maxlen={L}: {ms:.3f} ms/batch  GEMM {gf/1e9:.1f} GFLOP -> {gf/ms/1e9:.1f} TF/s "
-          f"(attn {attn_flops(cfg, lens)/1e9:.2f} GFLOP)  {nseq/ms*1e3:.0f} seq/s", flush=True)
+          f"(attn {res['attention_gflop']:.2f} GFLOP)  {nseq/ms*1e3:.0f} seq/s", flush=True)
     model.close()
+    if cpu_sample:
+        res["cpu_baseline"] = cpu_leg(cfg, w, seqs, out_kind, cpu_sample, threads)
+        print(f"    cpu: {res['cpu_baseline']['value']:.0f} seq/s on {threads} threads", flush=True)
+    return res
+
 
 if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default="")
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(16, avail))
+    c = 0 if a.no_cpu else 1
     rng = np.random.default_rng(1)
     q = rng.integers(8, 21, size=32)
-    run("encoder MiniLM-L6 (32 queries)", BertConfig.minilm_l6(), q, _native.BERT_OUT_MEAN)
-    run("encoder bge-base (32 queries)", BertConfig.bge_base(), q, _native.BERT_OUT_CLS)
     pairs = rng.integers(24 + 12, 64 + 12, size=3200)
-    run("rerank ms-marco-MiniLM (3200 pairs)", BertConfig.ms_marco_minilm_l6(), pairs, _native.BERT_OUT_PROBS, reps=5)
-    run("rerank ms-marco-MiniLM (320 pairs)", BertConfig.ms_marco_minilm_l6(), pairs[:320], _native.BERT_OUT_PROBS, reps=5)
-    run("rerank bge-reranker-base arch (3200 pairs)", BertConfig.bge_reranker_base(), pairs, _native.BERT_OUT_PROBS, reps=3)
+    out = [
+        run("query encoder, all-MiniLM-L6-v2 arch, 32 queries", BertConfig.minilm_l6(), q, _native.BERT_OUT_MEAN, cpu_sample=32 * c, threads=threads),
+        run("query encoder, bge-base-en-v1.5 arch, 32 queries", BertConfig.bge_base(), q, _native.BERT_OUT_CLS, cpu_sample=32 * c, threads=threads),
+        run("cross-encoder, ms-marco-MiniLM-L-6-v2 arch, 32 queries x 100 docs", BertConfig.ms_marco_minilm_l6(), pairs, _native.BERT_OUT_PROBS, reps=5, cpu_sample=200 * c, threads=threads),
+        run("cross-encoder, ms-marco-MiniLM-L-6-v2 arch, 32 queries x 10 docs", BertConfig.ms_marco_minilm_l6(), pairs[:320], _native.BERT_OUT_PROBS, reps=5),
+        run("cross-encoder, bge-reranker-base arch, 32 queries x 100 docs", BertConfig.bge_reranker_base(), pairs, _native.BERT_OUT_PROBS, reps=3, cpu_sample=100 * c, threads=threads),
+    ]
+    if a.json:
+        with open(a.json, "w") as fh:
+            json.dump({"fp32_mfma_peak_tflops": FP32_MFMA_PEAK_TF, "stages": out}, fh, indent=1)

@@ -263,6 +263,7 @@ def _executor(components, **kw):
     reg = ComponentRegistry()
     for name, comp in components.items():
         reg.register(name, comp)
+    kw.setdefault("DISABLE_CACHE_FOR_PROFILING", "true")
     return RetrievalExecutor(reg, PipelineSettings(retrieval_k=3, **kw)), reg
 
 
@@ -288,6 +289,25 @@ def test_executor_encode_path_and_rerank_replace_scores():
     items = ex._process_batch_sync(Batch(1, [_req(0), _req(1)]))
     assert [d.doc_id for d in items[0].docs] == [2, 1, 0]
     assert items[0].docs[0].score == pytest.approx(1 / 3)
+
+
+def test_executor_result_cache_hits_skip_the_index():
+    index = _Index()
+    ex, _ = _executor({"faiss_store": index}, DISABLE_CACHE_FOR_PROFILING="false")
+    b1 = Batch(1, [_req(0, [0.5] * 4), _req(1, [1.5] * 4)])
+    first = ex._process_batch_sync(b1)
+    assert len(index.calls) == 1 and index.calls[0][0].shape == (2, 4)
+    b2 = Batch(2, [_req(2, [1.5] * 4), _req(3, [2.5] * 4), _req(4, [0.5] * 4)])
+    second = ex._process_batch_sync(b2)
+    assert len(index.calls) == 2 and index.calls[1][0].shape == (1, 4)  # only the unseen embedding is searched
+    assert [d.doc_id for d in second[0].docs] == [d.doc_id for d in first[1].docs]
+    assert [d.doc_id for d in second[2].docs] == [d.doc_id for d in first[0].docs]
+    ex.clear_cache()
+    ex._process_batch_sync(Batch(3, [_req(5, [0.5] * 4)]))
+    assert len(index.calls) == 3
+    ex_off, _ = _executor({"faiss_store": index}, DISABLE_CACHE_FOR_PROFILING="true")
+    ex_off._process_batch_sync(b1); ex_off._process_batch_sync(b1)
+    assert len(index.calls) == 5
 
 
 def test_executor_end_to_end_through_scheduler():
