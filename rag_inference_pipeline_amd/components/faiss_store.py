@@ -10,6 +10,12 @@ tests/test_components.py:47, :92, :112, :133 and tests/test_retrieval_service.py
 What differs is only what sits underneath: rows live in HBM and `search` runs the gfx950
 scan + top-k kernels through the C ABI (rag_index_search).  There is no CPU path; on a machine
 without a HIP device `load()` raises.
+
+Multi-GPU: when the process belongs to an initialised torch.distributed group of more than one
+rank (one process per GPU), `load()` keeps only this rank's contiguous row range of the file
+(sharded.shard_range) and `search()` becomes collective — rank 0 serves requests exactly as before,
+the other ranks call `serve_forever()` and follow (the reference itself has no
+multi-device path).
 """
 
 from __future__ import annotations
@@ -35,6 +41,8 @@ class FAISSStore:
         self.settings = settings
         self.index_path = Path(settings.faiss_index_path)
         self._index = None  # rag_inference_pipeline_amd.flat_index.FlatIndex
+        self._sharded = None  # rag_inference_pipeline_amd.sharded.ShardedFlatIndex when world > 1
+        self._ntotal = 0
         self._is_loaded = False
 
     def load(self) -> None:
@@ -52,16 +60,33 @@ class FAISSStore:
             rows, metric = index_io.read_index_file(
                 self.index_path, default_metric, mmap=bool(getattr(self.settings, "faiss_use_mmap", False)))
             n, d = rows.shape
-            index = FlatIndex(d, metric, device=int(getattr(self.settings, "gpu_device", 0)))
-            index.reserve(n)
-            for lo in range(0, n, _ADD_CHUNK_ROWS):
-                index.add(np.ascontiguousarray(rows[lo:lo + _ADD_CHUNK_ROWS], dtype=np.float32))
+            device = int(getattr(self.settings, "gpu_device", 0))
+            rank, world = self._dist_rank_world()
+            row_lo, row_hi = 0, n
+            if world > 1:
+                from ..sharded import shard_range
+
+                row_lo, row_hi = shard_range(n, rank, world)
+                import torch
+
+                device = torch.cuda.current_device()  # the launcher binds one GPU per rank
+            index = FlatIndex(d, metric, device=device)
+            index.reserve(row_hi - row_lo)
+            for lo in range(row_lo, row_hi, _ADD_CHUNK_ROWS):
+                index.add(np.ascontiguousarray(rows[lo:min(lo + _ADD_CHUNK_ROWS, row_hi)], dtype=np.float32))
+            index.set_id_offset(row_lo)
             self._index = index
+            self._ntotal = n
+            if world > 1:
+                from ..sharded import ShardedFlatIndex
+
+                self._sharded = ShardedFlatIndex(index, metric, device=device)
             self._is_loaded = True
-            logger.info("FAISS index loaded successfully: %d vectors, dimension=%d", n, d)
+            logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (rows %d..%d on this rank)",
+                        n, d, row_lo, row_hi)
             # nprobe / precomputed tables (reference :84-100) have no meaning for an exhaustive
             # scan: every row is visited, which is the nprobe == nlist limit.
-            if n > 0:  # warm-up search, as the reference does (:103-107)
+            if row_hi > row_lo:  # warm-up search, as the reference does (:103-107); local, not collective
                 index.search(np.zeros((1, d), dtype=np.float32), 1)
         except FileNotFoundError:
             raise
@@ -83,14 +108,35 @@ class FAISSStore:
         embeddings = embeddings.astype("float32")
         logger.debug("Searching FAISS index with %d queries, k=%d", embeddings.shape[0], k)
         try:
+            if self._sharded is not None:
+                return self._sharded.leader_search(embeddings, k)
             return self._index.search(embeddings, k)
         except Exception:
             logger.exception("FAISS search failed")
             raise
 
+    @staticmethod
+    def _dist_rank_world() -> tuple[int, int]:
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return 0, 1
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def serve_forever(self) -> int:
+        """Ranks other than 0 of a sharded deployment: join the leader's searches until it unloads."""
+        if not self._is_loaded or self._sharded is None:
+            raise RuntimeError("FAISS index not loaded in sharded mode. Call load() first.")
+        return self._sharded.follower_loop()
+
     def unload(self) -> None:
         if self._is_loaded:
             logger.info("Unloading FAISS index")
+            if self._sharded is not None:
+                self._sharded.shutdown()
+                self._sharded = None
             if self._index is not None:
                 self._index.close()
             self._index = None
@@ -105,7 +151,7 @@ class FAISSStore:
     def index_size(self) -> int:
         if not self._is_loaded or self._index is None:
             return 0
-        return int(self._index.ntotal)
+        return int(self._ntotal)
 
     def __repr__(self) -> str:
         status = "loaded" if self._is_loaded else "not loaded"

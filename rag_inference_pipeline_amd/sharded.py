@@ -133,3 +133,46 @@ class ShardedFlatIndex:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         return s.cpu().numpy().copy(), i.cpu().numpy().copy()
+
+    # -- serving: rank 0 answers requests, the other ranks follow -------------------------------------
+    # The reference's retrieval node is ONE process (uvicorn) calling index.search(); with the corpus
+    # split over G ranks, rank 0 keeps that role and ships each batch's (nq, k, queries) to the
+    # followers, which sit in follower_loop() and join every collective search.
+    def _ctl_device(self) -> Any:
+        return self.device if self.backend == "nccl" else self._torch.device("cpu")
+
+    def leader_search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+        """Rank 0: broadcast the batch, run the collective search, return the merged result."""
+        if self.rank != 0:
+            raise RuntimeError("leader_search() is for rank 0; other ranks run follower_loop()")
+        torch, dist = self._torch, self._dist
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        head = torch.tensor([q.shape[0], int(k), q.shape[1]], dtype=torch.int64, device=self._ctl_device())
+        dist.broadcast(head, src=0, group=self.group)
+        qt = torch.from_numpy(q).to(self._ctl_device())
+        dist.broadcast(qt, src=0, group=self.group)
+        return self.search(q, k)
+
+    def follower_loop(self) -> int:
+        """Ranks > 0: serve collective searches until the leader sends shutdown(); returns the number
+        of batches served."""
+        if self.rank == 0:
+            raise RuntimeError("follower_loop() is for ranks other than 0")
+        torch, dist = self._torch, self._dist
+        served = 0
+        while True:
+            head = torch.zeros(3, dtype=torch.int64, device=self._ctl_device())
+            dist.broadcast(head, src=0, group=self.group)
+            nq, k, d = (int(v) for v in head.tolist())
+            if nq <= 0:
+                return served
+            qt = torch.empty((nq, d), dtype=torch.float32, device=self._ctl_device())
+            dist.broadcast(qt, src=0, group=self.group)
+            self.search(qt.cpu().numpy(), k)
+            served += 1
+
+    def shutdown(self) -> None:
+        """Rank 0: release the followers from follower_loop()."""
+        if self.rank == 0 and self.world > 1:
+            head = self._torch.zeros(3, dtype=self._torch.int64, device=self._ctl_device())
+            self._dist.broadcast(head, src=0, group=self.group)

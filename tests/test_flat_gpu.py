@@ -174,3 +174,55 @@ def test_full_size_properties_10m_768(gpu_required):
             if Ds[b, 0] > D[b, k - 1] or (Ds[b, 0] == D[b, k - 1] and Is[b, 0] < I[b, k - 1]):
                 assert Is[b, 0] in I[b]
     idx.close()
+
+
+def test_randomised_shapes_match_oracle(gpu_required):
+    """40 seeded random (N, d, nq, k, metric) draws, including column-chunked d, multi-round k,
+    multi-pass nq, duplicated rows and un-normalised data."""
+    rng = np.random.default_rng(20261004)
+    dims = [8, 24, 64, 100, 200, 384, 520, 768, 1032, 1536]
+    for trial in range(40):
+        d = int(rng.choice(dims))
+        N = int(rng.integers(1, 12_000 if d <= 768 else 3_000))
+        nq = int(rng.integers(1, 71))
+        k = int(rng.choice([1, 2, 7, 10, 33, 100, 130, 260]))
+        metric = int(rng.integers(0, 2))
+        X = rng.standard_normal((N, d), dtype=np.float32) * np.float32(rng.choice([0.1, 1.0, 30.0]))
+        if trial % 4 == 0 and N > 10:  # exact duplicates -> ties
+            X[N // 2:] = X[: N - N // 2]
+        Q = rng.standard_normal((nq, d), dtype=np.float32)
+        idx = _index(X, metric)
+        D, I = idx.search(Q, k)
+        Do, Io = oracle.search(X, Q, k, metric)
+        np.testing.assert_array_equal(I, Io, err_msg=f"trial {trial}: N={N} d={d} nq={nq} k={k} metric={metric}")
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32), err_msg=f"trial {trial}")
+        idx.close()
+
+
+def test_concurrent_searches_on_one_handle(gpu_required):
+    """The reference's scheduler runs batches concurrently on worker threads
+    (batch_scheduler.py:286-288): one handle, many threads, every answer still exact."""
+    import threading
+    rng = np.random.default_rng(3)
+    X = _unit(rng, 30_000, 384)
+    idx = _index(X)
+    queries = [_unit(rng, int(n), 384) for n in (1, 32, 7, 40, 16, 32, 3, 25)]
+    want = [oracle.search(X, q, 10) for q in queries]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                D, I = idx.search(queries[i], 10)
+                np.testing.assert_array_equal(I, want[i][1])
+                np.testing.assert_array_equal(D, want[i][0])
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, exc))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    idx.close()

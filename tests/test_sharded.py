@@ -72,3 +72,30 @@ def test_sharded_search_gloo_cpu_rehearsal(tmp_path, world, metric):
 def test_sharded_search_real_kernels_two_ranks_one_gpu(gpu_required, tmp_path, world, metric, k):
     n, d, nq = 40_003, 384, 32
     _check(_launch("gpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
+
+
+@pytest.mark.gpu
+def test_faiss_store_sharded_serving_mode(gpu_required, tmp_path):
+    """FAISSStore under torch.distributed: every rank loads its row range of the same file, rank 0
+    serves search() as usual, the other ranks follow until it unloads."""
+    from rag_inference_pipeline_amd import index_io
+    n, d, world = 30_001, 384, 3
+    X = oracle.synth_rows(1234, 0, n, d)
+    path = tmp_path / "faiss_index.bin"
+    index_io.write_flat_index(path, X, 0)
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"store{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_store_worker.py"), str(r), str(world), str(port), str(path), out, str(d)],
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lead = np.load(outs[0])
+    for i, (nq, k) in enumerate([(1, 10), (32, 10), (5, 100)]):
+        D, I = oracle.search(X, oracle.synth_rows(4321 + i, 0, nq, d), k)
+        np.testing.assert_array_equal(lead[f"I{i}"], I)
+        np.testing.assert_array_equal(lead[f"D{i}"], D)
+    assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])
