@@ -58,9 +58,12 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask) {
     return ((u64)hi << 32) | lo;
 }
 
-// Wave-level bitonic sort, descending over index i = e*64 + lane, E keys per lane.
-template <int E>
-__device__ __forceinline__ void wave_sort_desc(u64 (&key)[E], int lane) {
+// Wave-level bitonic sort, descending over index i = e*64 + lane, E keys per lane, of NQ independent
+// key sets at once.  Each compare-exchange stage costs a ds_bpermute round trip per set; running the
+// wave's NQ sets through the network together overlaps those latencies (one set at a time a
+// compaction of 4 queries took ~6 us, i.e. most of the scan's fixed overhead on small shards).
+template <int E, int NQ>
+__device__ __forceinline__ void wave_sort_desc(u64 (&key)[NQ][E], int lane) {
 #pragma unroll
     for (int size = 2; size <= 64 * E; size <<= 1) {
 #pragma unroll
@@ -68,23 +71,32 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&key)[E], int lane) {
             if (stride >= 64) {
                 const int se = stride >> 6;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if ((e & se) == 0) {
-                        const bool up = (((e * 64) & size) == 0);  // size >= 128 here: lane-independent
-                        u64 a = key[e], b = key[e | se];
-                        u64 hi = umax64(a, b), lo = umin64(a, b);
-                        key[e] = up ? hi : lo;
-                        key[e | se] = up ? lo : hi;
+                for (int s = 0; s < NQ; ++s) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & se) == 0) {
+                            const bool up = (((e * 64) & size) == 0);  // size >= 128 here: lane-independent
+                            u64 a = key[s][e], b = key[s][e | se];
+                            u64 hi = umax64(a, b), lo = umin64(a, b);
+                            key[s][e] = up ? hi : lo;
+                            key[s][e | se] = up ? lo : hi;
+                        }
                     }
                 }
             } else {
+                u64 other[NQ][E];
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = e * 64 + lane;
-                    const bool up = ((i & size) == 0);
-                    const bool lower = ((lane & stride) == 0);
-                    u64 other = shfl_xor_u64(key[e], stride);
-                    key[e] = (lower == up) ? umax64(key[e], other) : umin64(key[e], other);
+                for (int s = 0; s < NQ; ++s)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[s][e] = shfl_xor_u64(key[s][e], stride);
+                const bool lower = ((lane & stride) == 0);
+#pragma unroll
+                for (int s = 0; s < NQ; ++s) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool up = (((e * 64 + lane) & size) == 0);
+                        key[s][e] = (lower == up) ? umax64(key[s][e], other[s][e]) : umin64(key[s][e], other[s][e]);
+                    }
                 }
             }
         }
@@ -145,15 +157,21 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (qrow < p.nq) {
             const float* src = p.Q + (size_t)qrow * p.d + col;
+            if ((p.d & 3) == 0 && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
+                v = *reinterpret_cast<const f32x4*>(src);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j < p.d) v[j] = src[j];
+                for (int j = 0; j < 4; ++j)
+                    if (col + j < p.d) v[j] = src[j];
+            }
         }
         qf[idx] = v;
     }
     if (tid < kQT) {
         cnt[tid] = 0;
-        thr[tid] = -__builtin_inff();
+        // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
+        // they never enter the slow path (left at -inf they tie forever and double the scan time)
+        thr[tid] = tid < p.nq ? -__builtin_inff() : __builtin_inff();
     }
     if (tid < 4) flag[tid] = 0;
     __syncthreads();
@@ -318,23 +336,34 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
             if (tid == 0) flag[(seq + 2) & 3] = 0;
             ++seq;
             if (!need) break;
-            for (int q = wave; q < kQT; q += kScanWaves) {
-                const uint32_t n = min(cnt[q], (uint32_t)C);
-                if (n > (uint32_t)p.k || cnt[q] > (uint32_t)C) {
-                    u64 kk[E];
+            {   // this wave's queries (wave, wave + NW, ...) go through the sort network together
+                constexpr int NQW = (kQT + kScanWaves - 1) / kScanWaves;
+                u64 kk[NQW][E];
+                uint32_t nn[NQW];
+#pragma unroll
+                for (int j = 0; j < NQW; ++j) {
+                    const int q = wave + kScanWaves * j;
+                    nn[j] = q < kQT ? min(cnt[q], (uint32_t)C) : 0u;
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         const uint32_t idx = e * 64 + lane;
-                        kk[e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+                        kk[j][e] = idx < nn[j] ? keys[(size_t)q * C + idx] : 0ull;
                     }
-                    wave_sort_desc<E>(kk, lane);
+                }
+                wave_sort_desc<E, NQW>(kk, lane);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int idx = e * 64 + lane;
-                        if (idx < p.k) keys[(size_t)q * C + idx] = kk[e];
-                        if (idx == p.k - 1) thr[q] = n >= (uint32_t)p.k ? unord32((uint32_t)(kk[e] >> 32)) : -__builtin_inff();
+                for (int j = 0; j < NQW; ++j) {
+                    const int q = wave + kScanWaves * j;
+                    if (q < kQT && nn[j] > 0) {  // sorting a short buffer is harmless: cnt and thr stay consistent
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int idx = e * 64 + lane;
+                            if (idx < p.k) keys[(size_t)q * C + idx] = kk[j][e];
+                            if (idx == p.k - 1)
+                                thr[q] = nn[j] >= (uint32_t)p.k ? unord32((uint32_t)(kk[j][e] >> 32)) : -__builtin_inff();
+                        }
+                        if (lane == 0) cnt[q] = min(nn[j], (uint32_t)p.k);
                     }
-                    if (lane == 0) cnt[q] = min(n, (uint32_t)p.k);
                 }
             }
             __syncthreads();
@@ -363,20 +392,31 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 
     if (p.acc_out) return;
     // ---- epilogue: sort every buffer, emit k keys per query for this workgroup
-    for (int q = wave; q < kQT; q += kScanWaves) {
-        const uint32_t n = min(cnt[q], (uint32_t)C);
-        u64 kk[E];
+    {
+        constexpr int NQW = (kQT + kScanWaves - 1) / kScanWaves;
+        u64 kk[NQW][E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const uint32_t idx = e * 64 + lane;
-            kk[e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+        for (int j = 0; j < NQW; ++j) {
+            const int q = wave + kScanWaves * j;
+            const uint32_t n = q < kQT ? min(cnt[q], (uint32_t)C) : 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t idx = e * 64 + lane;
+                kk[j][e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+            }
         }
-        wave_sort_desc<E>(kk, lane);
-        u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * p.k;
+        wave_sort_desc<E, NQW>(kk, lane);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int idx = e * 64 + lane;
-            if (idx < p.k) out[idx] = kk[e];
+        for (int j = 0; j < NQW; ++j) {
+            const int q = wave + kScanWaves * j;
+            if (q < kQT) {
+                u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * p.k;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int idx = e * 64 + lane;
+                    if (idx < p.k) out[idx] = kk[j][e];
+                }
+            }
         }
     }
 }
