@@ -1,5 +1,8 @@
+"""Ablations of the scan kernel: matrix work removed (load stream only) / corpus cache-resident
+(matrix pipe only), timed against the product build, one subprocess per library."""
 import os, sys, subprocess
 sys.path.insert(0, ".")
+from scripts._sidelib import build
 code = r'''
 import os, sys
 sys.path.insert(0, ".")
@@ -17,8 +20,9 @@ for w, r in [(8, 8), (16, 8), (8, 4)]:
     ms, n = idx.profile(reset=True); idx.profile_enable(False)
     print(f"  {os.environ.get('VARIANT')}: waves={w} ring={r}: {ms/n:.3f} ms -> {4.0*N*d/(ms/n*1e-3)/1e9:.0f} GB/s-equivalent", flush=True)
 '''
-for variant, lib in [("product", ""), ("NO_MFMA", "rag_inference_pipeline_amd/csrc/exp/librag_amd_NO_MFMA.so"),
-                     ("L2_WINDOW", "rag_inference_pipeline_amd/csrc/exp/librag_amd_L2_WINDOW.so")]:
+for variant, lib in [("product", build("TUNING", ["RAGK_TUNING"])),
+                     ("NO_MFMA", build("NO_MFMA", ["RAGK_TUNING", "RAGK_ABLATE_NO_MFMA"])),
+                     ("L2_WINDOW", build("L2_WINDOW", ["RAGK_TUNING", "RAGK_ABLATE_L2_WINDOW"]))]:
     env = dict(os.environ, VARIANT=variant)
     if lib: env["RAG_AMD_LIB"] = os.path.abspath(lib)
     subprocess.run([sys.executable, "-c", code], env=env, check=False)

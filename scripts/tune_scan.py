@@ -2,6 +2,8 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
+from scripts._sidelib import build
+os.environ["RAG_AMD_LIB"] = build("TUNING", ["RAGK_TUNING"])  # 12/16-wave and ring-12/16 variants + env overrides
 from rag_inference_pipeline_amd.flat_index import FlatIndex
 from oracle import flat as oracle
 
