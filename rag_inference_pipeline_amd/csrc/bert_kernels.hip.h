@@ -13,7 +13,8 @@
 //
 //   embed_ln_kernel     word + position + type embedding, LayerNorm                (1 wave / token)
 //   gemm_nt_kernel      C = A · Wᵀ + bias [+ residual] [activation], 128x128x32 tiles, fp32 MFMA
-//   attention_kernel    softmax(QKᵀ/√dh)V per (sequence, head), online softmax     (1 wave / 64 rows)
+//   attention_mfma_kernel softmax(QKᵀ/√dh)V per (sequence, head, 32 rows) on fp32 MFMA (1 wave / block)
+//   attention_kernel    the same on the VALU (kept as the reference implementation for tests)
 //   splitk_bias_res_ln  y = LN(sum of split-K slabs + bias + residual)              (1 wave / token)
 //   pool_kernel         mean / CLS pooling + optional L2 normalisation              (1 block / seq)
 //   gather_rows_kernel  first-token rows for the classifier head
@@ -495,28 +496,34 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const i
         }
         __syncthreads();
         for (int j = 0; j < nj; ++j) {
-            float sc = 0.f;
+            // four independent partial dot products (a single 32..64-long fmaf chain is pure latency)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int c = 0; c < DH; c += 4) {
                 const f32x4 kv = *reinterpret_cast<const f32x4*>(&Ks[j * DH + c]);  // broadcast read
-                sc = __builtin_fmaf(q[c], kv[0], sc);
-                sc = __builtin_fmaf(q[c + 1], kv[1], sc);
-                sc = __builtin_fmaf(q[c + 2], kv[2], sc);
-                sc = __builtin_fmaf(q[c + 3], kv[3], sc);
+                s0 = __builtin_fmaf(q[c], kv[0], s0);
+                s1 = __builtin_fmaf(q[c + 1], kv[1], s1);
+                s2 = __builtin_fmaf(q[c + 2], kv[2], s2);
+                s3 = __builtin_fmaf(q[c + 3], kv[3], s3);
             }
-            const float mnew = fmaxf(mx, sc);
-            const float alpha = expf(mx - mnew);  // exp(-inf) = 0 on the first key
-            const float pj = expf(sc - mnew);
-            den = den * alpha + pj;
+            const float sc = (s0 + s1) + (s2 + s3);
+            if (sc > mx) {  // new running maximum: rescale what has been accumulated (rare after a few keys)
+                const float alpha = expf(mx - sc);  // exp(-inf) = 0 on the first key
+                den *= alpha;
+#pragma unroll
+                for (int c = 0; c < DH; ++c) o[c] *= alpha;
+                mx = sc;
+            }
+            const float pj = expf(sc - mx);
+            den += pj;
 #pragma unroll
             for (int c = 0; c < DH; c += 4) {
                 const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vs[j * DH + c]);
-                o[c] = __builtin_fmaf(o[c], alpha, pj * vv[0]);
-                o[c + 1] = __builtin_fmaf(o[c + 1], alpha, pj * vv[1]);
-                o[c + 2] = __builtin_fmaf(o[c + 2], alpha, pj * vv[2]);
-                o[c + 3] = __builtin_fmaf(o[c + 3], alpha, pj * vv[3]);
+                o[c] = __builtin_fmaf(pj, vv[0], o[c]);
+                o[c + 1] = __builtin_fmaf(pj, vv[1], o[c + 1]);
+                o[c + 2] = __builtin_fmaf(pj, vv[2], o[c + 2]);
+                o[c + 3] = __builtin_fmaf(pj, vv[3], o[c + 3]);
             }
-            mx = mnew;
         }
     }
     if (valid) {
@@ -527,6 +534,125 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const i
             f32x4 v = {o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};
             *reinterpret_cast<f32x4*>(orow + c) = v;
         }
+    }
+}
+
+// ---- attention on the matrix pipe -------------------------------------------------------------------
+// One wave per (sequence, head, 32 query rows); fp32 MFMA for both products, online softmax between
+// them, everything arranged so that the LANE is the query:
+//   Sᵀ[key][query] = K·Qᵀ      A = K fragment (LDS), B = Q fragment (registers, pre-scaled by 1/√dh)
+//                               -> lane (r,h) holds Sᵀ for query r and the 16 keys 8(i>>2)+(i&3)+4h
+//   softmax over keys           = over the lane's 16 registers, its partner lane r+32, and key tiles
+//   Oᵀ[dh][query] += Vᵀ·Pᵀ      B = the probabilities exactly as they sit in the accumulator (register i of
+//                               lane (r,h) IS Pᵀ[key(i,h)][r], the k-slot layout MFMA wants), A = V read
+//                               from LDS by column -> no shuffle, no transpose of P.
+// The VALU version this replaces issued ~200 vector instructions per key per wave and ran at 40 % of the
+// VALU issue rate (12 % of cross-encoder time); here a 32-key tile is 16..32 + 16..32 MFMAs.
+template <int DH>
+__global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int* cu, float* ctx, int H, int heads,
+                                                            float scale) {
+    constexpr int KLD = DH + 4;  // padded K rows: conflict-free ds_read_b128 fragments
+    __shared__ __attribute__((aligned(16))) float Ks[32 * KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * DH];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int s = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    if (qb * 32 >= L) return;
+    const int qidx = qb * 32 + r;
+    const bool qvalid = qidx < L;
+    const size_t ld = (size_t)3 * H;
+
+    // Q fragments: lane (r,h) holds Q[qidx][8 s + 4 h .. + 3] for every 8-column step s
+    f32x4 qf[DH / 8];
+    {
+        const float* qrow = qkv + (size_t)(t0 + (qvalid ? qidx : L - 1)) * ld + head * DH + 4 * h;
+#pragma unroll
+        for (int st = 0; st < DH / 8; ++st) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(qrow + 8 * st);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = qvalid ? v[e] * scale : 0.f;
+            qf[st] = v;
+        }
+    }
+    f32x16 oT[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oT[dt][i] = 0.f;
+    float mx = -__builtin_inff(), den = 0.f;
+
+    const int n_kt = (L + 31) / 32;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * 32, nk = min(32, L - k0);
+        __syncthreads();  // previous tile's LDS reads are done (one wave: this is just a waitcnt)
+        for (int idx = lane; idx < 32 * (DH / 4); idx += 64) {
+            const int j = idx / (DH / 4), c = (idx % (DH / 4)) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+            if (j < nk) {
+                const float* base = qkv + (size_t)(t0 + k0 + j) * ld + head * DH + c;
+                kv = *reinterpret_cast<const f32x4*>(base + H);
+                vv = *reinterpret_cast<const f32x4*>(base + 2 * H);
+            }
+            *reinterpret_cast<f32x4*>(&Ks[j * KLD + c]) = kv;
+            *reinterpret_cast<f32x4*>(&Vs[j * DH + c]) = vv;
+        }
+        __syncthreads();
+
+        // Sᵀ tile
+        f32x16 sT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sT[i] = 0.f;
+#pragma unroll
+        for (int st = 0; st < DH / 8; ++st) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[r * KLD + 8 * st + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[st][t], sT, 0, 0, 0);
+        }
+        // mask keys beyond the sequence, running max over this lane's keys and its partner's
+        float tmax = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (key >= nk) sT[i] = -__builtin_inff();
+            tmax = fmaxf(tmax, sT[i]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mx, tmax);  // finite: every tile has at least one valid key
+        const float alpha = expf(mx - mnew);  // 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            sT[i] = expf(sT[i] - mnew);  // masked keys: exp(-inf) = 0
+            psum += sT[i];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * alpha + psum;
+        mx = mnew;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oT[dt][i] *= alpha;
+        // Oᵀ += Vᵀ Pᵀ : MFMA i consumes the key pair (key(i,0), key(i,1)) = registers i of the two halves
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                const float vf = Vs[key * DH + dt * 32 + r];
+                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sT[i], oT[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / den;
+        float* orow = ctx + (size_t)(t0 + qidx) * H + head * DH;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are dh rows 8g + 4h + 0..3: one 16-byte store
+                f32x4 v = {oT[dt][4 * g] * inv, oT[dt][4 * g + 1] * inv, oT[dt][4 * g + 2] * inv, oT[dt][4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(orow + dt * 32 + 8 * g + 4 * h) = v;
+            }
     }
 }
 

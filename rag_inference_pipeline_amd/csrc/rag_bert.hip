@@ -4,6 +4,7 @@
 // Weights stay in caller-owned device memory (PyTorch-ROCm tensors); this file owns only the
 // activation workspace.  No CPU compute path.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -36,6 +37,7 @@ struct rag_bert {
     rag_bert_config cfg{};
     int device = 0;
     int n_cus = 256;
+    bool valu_attention = false;  // RAG_AMD_VALU_ATTENTION=1: the VALU attention kernel (A/B checks)
     std::vector<const float*> w;
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -196,15 +198,23 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     const int act = map_act(c.act);
     const float scale = 1.0f / sqrtf((float)dh);
     const dim3 agrid((max_len + 63) / 64, heads, nseq);
+    const dim3 mgrid((max_len + 31) / 32, heads, nseq);
     for (int l = 0; l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
         // QKV projection
         rc = launch_gemm(h->x, H, lw[0], H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
         if (rc) return rc;
-        if (dh == 32)
-            attention_kernel<32><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
-        else
-            attention_kernel<64><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        if (h->valu_attention) {
+            if (dh == 32)
+                attention_kernel<32><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+            else
+                attention_kernel<64><<<agrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        } else {
+            if (dh == 32)
+                attention_mfma_kernel<32><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+            else
+                attention_mfma_kernel<64><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        }
         RAGC_HIP_TRY(hipGetLastError());
         // attention output projection + residual + LayerNorm (x is both residual and destination:
         // each token's row is read and written by the same wave of the LayerNorm kernel)
@@ -298,6 +308,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
+    const char* va = getenv("RAG_AMD_VALU_ATTENTION");
+    h->valu_attention = va && *va == '1';
     *out = h;
     return RAG_OK;
 }
