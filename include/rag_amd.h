@@ -177,6 +177,7 @@ typedef struct rag_bert_config {
     int32_t head;          /* RAG_HEAD_* */
     int32_t n_labels;      /* classifier outputs (1 for the rerankers) */
     float ln_eps;
+    int32_t gemm_f16;      /* 1: big-batch GEMMs take fp16 inputs (fp32 accumulate), as the reference's GPU reranker; 0: fp32 */
 } rag_bert_config;
 
 /* Number of entries rag_bert_create expects in `weights` for a config:
@@ -186,6 +187,7 @@ typedef struct rag_bert_config {
  *     qkv_w [3H][H] (q;k;v rows) qkv_b [3H]  attn_out_w [H][H] attn_out_b [H]  ln1_gamma ln1_beta
  *     ffn_in_w [I][H] ffn_in_b [I]  ffn_out_w [H][I] ffn_out_b [H]  ln2_gamma ln2_beta
  *   then, if head != RAG_HEAD_NONE: head_dense_w [H][H] head_dense_b [H] head_out_w [n_labels][H] head_out_b
+ *   then, if gemm_f16: per layer 4 fp16 copies (qkv_w, attn_out_w, ffn_in_w, ffn_out_w), same shapes
  * All fp32, torch.nn.Linear layout (W[out][in], row-major), device memory on `device`.  The library
  * does not copy them: the caller (PyTorch-ROCm tensors) keeps them alive until rag_bert_destroy. */
 int32_t rag_bert_weight_count(const rag_bert_config* cfg);

@@ -46,6 +46,7 @@ class BertConfig:
     n_labels: int = 1
     ln_eps: float = 1e-12
     pooling: str = "mean"          # sentence-embedding pooling: "mean" | "cls"
+    gemm_dtype: str = "f32"        # "f16": big-batch GEMMs take fp16 inputs (the reference's GPU reranker precision)
     extra: dict[str, Any] = field(default_factory=dict)
 
     # -- the model families BASELINE.json names (architecture facts are upstream model cards) ------
@@ -92,7 +93,7 @@ class BertConfig:
         head = {"none": _native.HEAD_NONE, "bert": _native.HEAD_BERT, "roberta": _native.HEAD_ROBERTA}[self.head]
         return _native.BertConfigStruct(self.vocab_size, self.hidden, self.n_layers, self.n_heads, self.intermediate,
                                         self.max_positions, self.type_vocab, self.pos_offset, _ACTS[self.act], head,
-                                        self.n_labels, self.ln_eps)
+                                        self.n_labels, self.ln_eps, 1 if self.gemm_dtype == "f16" else 0)
 
     def weight_shapes(self) -> dict[str, tuple[int, ...]]:
         H, I = self.hidden, self.intermediate
@@ -243,6 +244,14 @@ class BertModel:
         if cfg.head != "none":
             order += list(HEAD_KEYS)
         ptrs = [self._tensors[k].data_ptr() if k in self._tensors else 0 for k in order]
+        if cfg.gemm_dtype == "f16":  # fp16 copies of the four GEMM weights of every layer
+            for l in range(cfg.n_layers):
+                for k in ("qkv_w", "attn_out_w", "ffn_in_w", "ffn_out_w"):
+                    t16 = self._tensors[f"layer{l}.{k}"].to(torch.float16).contiguous()
+                    self._tensors[f"layer{l}.{k}.f16"] = t16
+                    ptrs.append(t16.data_ptr())
+        elif cfg.gemm_dtype != "f32":
+            raise ValueError(f"gemm_dtype must be 'f32' or 'f16', got {cfg.gemm_dtype!r}")
         table = (C.c_void_p * len(ptrs))(*ptrs)
         struct = cfg.to_struct()
         assert self._lib.rag_bert_weight_count(C.byref(struct)) == len(ptrs)

@@ -50,6 +50,7 @@ class Reranker:
             from ..model_source import resolve_model
 
             cfg, weights, tokenizer, max_len = resolve_model(self.model_name, "reranker")
+            cfg.gemm_dtype = str(getattr(self.settings, "reranker_dtype", "f32")).lower().replace("fp", "f")
             self.model = BertModel(cfg, weights, device=int(getattr(self.settings, "gpu_device", 0)))
             self.tokenizer, self._max_len = tokenizer, max_len
             self._loaded = True

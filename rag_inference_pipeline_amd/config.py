@@ -66,6 +66,9 @@ class PipelineSettings(BaseModel):
     # -- knobs that exist only in this build
     gpu_device: int = Field(default=0, alias="RAG_AMD_DEVICE")
     faiss_metric: str = Field(default="ip", alias="RAG_AMD_METRIC")  # for files that carry no metric
+    # "f16" = fp16-input GEMMs for the cross-encoder, the precision the reference uses on a GPU
+    # (reranker.py:91-93); "f32" (default) matches the CPU path the parity tests are held to
+    reranker_dtype: str = Field(default="f32", alias="RAG_AMD_RERANKER_DTYPE")
 
     @classmethod
     def from_env(cls, env: dict[str, str] | None = None, **overrides: Any) -> "PipelineSettings":

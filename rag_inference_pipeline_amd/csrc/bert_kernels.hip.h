@@ -306,6 +306,120 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     }
 }
 
+// Half-precision-input GEMM (opt-in, big M only): A is fp32 in memory and rounded to fp16 while it is
+// staged, W is an fp16 copy of the weights, products accumulate in fp32 on v_mfma_f32_32x32x16_f16
+// (16x the fp32 matrix rate), bias / activation / residual / output stay fp32.  This is the precision
+// the reference itself runs the reranker at on a GPU (reranker.py:91-93: float16 on cuda); the default
+// build path stays fp32 because the parity bar is the CPU fp32 path.
+// 128 x 128 x 64 tiles, 4 waves (2 x 2) of 64 x 64; LDS rows are 64 + 8 halfs = 144 B (the same
+// 36-dword stride as the fp32 kernel: conflict-free 16-byte fragment reads).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int HBK = 64, HLD = 72;
+
+struct GemmF16Params {
+    const float* A;       // [M][lda] fp32
+    const _Float16* W;    // [N][ldw] fp16
+    const float* bias;
+    const float* R;
+    float* C;
+    int M, N, K;          // K % 64 == 0
+    int lda, ldw, ldr, ldc;
+    int act;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[128 * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[128 * HLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+
+    // A staging: 128 rows x 16 float4 -> thread (row = tid/16 + 16 j, float4 col = tid%16), 8 passes
+    // W staging: 128 rows x  8 f16x8  -> thread (row = tid/8  + 32 j, f16x8  col = tid%8),  4 passes
+    const int arow = tid >> 4, acol = (tid & 15) * 4;
+    const int wrow = tid >> 3, wcol = (tid & 7) * 8;
+    const float* ag[8];
+    const _Float16* wg[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int am = m0 + arow + 16 * j;
+        am = am < p.M ? am : p.M - 1;
+        ag[j] = p.A + (size_t)am * p.lda + acol;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int wr = n0 + wrow + 32 * j;
+        wr = wr < p.N ? wr : p.N - 1;
+        wg[j] = p.W + (size_t)wr * p.ldw + wcol;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    f32x4 ra[8];
+    f16x8 rw[4];
+    const int nk = p.K / HBK;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const f16x8*>(wg[j]);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f16x4 hv = {(_Float16)ra[j][0], (_Float16)ra[j][1], (_Float16)ra[j][2], (_Float16)ra[j][3]};
+            *reinterpret_cast<f16x4*>(&As[(arow + 16 * j) * HLD + acol]) = hv;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8*>(&Ws[(wrow + 32 * j) * HLD + wcol]) = rw[j];
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)(kt + 1) * HBK);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const f16x8*>(wg[j] + (size_t)(kt + 1) * HBK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {  // lane (r,h) feeds A[row r][16 ks + 8 h .. + 7]
+            f16x8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                af[a] = *reinterpret_cast<const f16x8*>(&As[(wm * 64 + a * 32 + r) * HLD + 16 * ks + 8 * h]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                bf[b] = *reinterpret_cast<const f16x8*>(&Ws[(wn * 64 + b * 32 + r) * HLD + 16 * ks + 8 * h]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + r;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (m < p.M) {
+                    float v = apply_act(acc[a][b][i] + bias, p.act);
+                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
+                    p.C[(size_t)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
 // Small-M GEMM: 64 x 64 x 64 tiles, EIGHT waves.  Waves 0-3 (2 x 2 over the tile) multiply columns 0-31 of
 // every staged K-tile, waves 4-7 columns 32-63, so each SIMD holds two waves whose LDS waits and barrier
 // waits hide behind each other's MFMAs (with one wave per SIMD half of each K-step was exposed latency);

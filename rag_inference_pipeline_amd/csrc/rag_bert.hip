@@ -18,9 +18,8 @@ namespace {
 constexpr int kPerLayer = 12;
 constexpr int kEmbEntries = 5;
 
-int weight_count(const rag_bert_config& c) {
-    return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0);
-}
+int f16_base(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
+int weight_count(const rag_bert_config& c) { return f16_base(c) + (c.gemm_f16 ? 4 * c.n_layers : 0); }
 
 int map_act(int act) {
     switch (act) {
@@ -101,10 +100,18 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
     return RAG_OK;
 }
 
-// Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip.
-int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, int ldr, float* C,
-                int ldc, int M, int N, int K, int act, hipStream_t st) {
+// Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip; big M
+// takes fp16 inputs when the model was created with gemm_f16 and an fp16 copy of W is supplied.
+int launch_gemm(const float* A, int lda, const float* W, const _Float16* W16, int ldw, const float* bias, const float* R,
+                int ldr, float* C, int ldc, int M, int N, int K, int act, hipStream_t st) {
     if (M <= 0) return RAG_OK;
+    if (M > 1024 && W16 && K % ragb::HBK == 0) {
+        ragb::GemmF16Params g{A, W16, bias, R, C, M, N, K, lda, ldw, ldr, ldc, act};
+        dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+        ragb::gemm_nt_f16_kernel<<<grid, dim3(256), 0, st>>>(g);
+        RAGC_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
     ragb::GemmParams g;
     g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -129,7 +136,7 @@ int launch_gemm(const float* A, int lda, const float* W, int ldw, const float* b
 // kMaxSplits * M * N floats) reduced by the LayerNorm kernel; big M: fused-epilogue GEMM into `part`,
 // then LayerNorm.
 constexpr int kMaxSplits = ragb::kMaxSplitK;
-int launch_gemm_ln(const float* A, int lda, const float* W, int ldw, const float* bias, const float* R, float* part,
+int launch_gemm_ln(const float* A, int lda, const float* W, const _Float16* W16, int ldw, const float* bias, const float* R, float* part,
                    const float* ln_g, const float* ln_b, float* y, int M, int N, int K, float eps, int n_cus,
                    hipStream_t st) {
     if (M <= 0) return RAG_OK;
@@ -139,7 +146,7 @@ int launch_gemm_ln(const float* A, int lda, const float* W, int ldw, const float
         splits = std::max(1, std::min({kMaxSplits, (n_cus + tiles - 1) / tiles, K / (4 * ragb::GBK)}));
     }
     if (splits == 1) {
-        int rc = launch_gemm(A, lda, W, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
+        int rc = launch_gemm(A, lda, W, W16, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
         if (rc) return rc;
         ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, 1, nullptr, nullptr, ln_g, ln_b, y, M, N, eps);
     } else {
@@ -201,8 +208,10 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     const dim3 mgrid((max_len + 31) / 32, heads, nseq);
     for (int l = 0; l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
+        const _Float16* const* lh = c.gemm_f16 ? reinterpret_cast<const _Float16* const*>(w + f16_base(c) + 4 * l) : nullptr;
+        auto w16 = [&](int i) -> const _Float16* { return lh ? lh[i] : nullptr; };
         // QKV projection
-        rc = launch_gemm(h->x, H, lw[0], H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
+        rc = launch_gemm(h->x, H, lw[0], w16(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
         if (rc) return rc;
         if (h->valu_attention) {
             if (dh == 32)
@@ -218,12 +227,12 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         RAGC_HIP_TRY(hipGetLastError());
         // attention output projection + residual + LayerNorm (x is both residual and destination:
         // each token's row is read and written by the same wave of the LayerNorm kernel)
-        rc = launch_gemm_ln(h->ctx, H, lw[2], H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
+        rc = launch_gemm_ln(h->ctx, H, lw[2], w16(1), H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
         // feed-forward: act(x W1ᵀ + b1) W2ᵀ + b2 + residual, LayerNorm
-        rc = launch_gemm(h->x, H, lw[6], H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
+        rc = launch_gemm(h->x, H, lw[6], w16(2), H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
         if (rc) return rc;
-        rc = launch_gemm_ln(h->ffn, I, lw[8], I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
+        rc = launch_gemm_ln(h->ffn, I, lw[8], w16(3), I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
     }
 
@@ -242,7 +251,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             const int total = nseq * H;
             gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
             RAGC_HIP_TRY(hipGetLastError());
-            rc = launch_gemm(h->pooled, H, hw[0], H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
+            rc = launch_gemm(h->pooled, H, hw[0], nullptr, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
             if (rc) return rc;
             const bool probs = out_kind == RAG_BERT_OUT_PROBS;
             head_out_kernel<<<dim3(nseq, c.n_labels), dim3(64), 0, st>>>(h->pooled2, hw[2], hw[3], probs ? h->logits : out,

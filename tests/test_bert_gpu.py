@@ -103,3 +103,28 @@ def test_bert_error_contract(gpu_required):
                   random_weights(BertConfig(vocab_size=50, hidden=96, n_layers=1, n_heads=2, intermediate=64,
                                             max_positions=16), 0))
     model.close()
+
+
+def test_cross_encoder_fp16_gemm_mode_tracks_fp32_oracle(gpu_required):
+    """Opt-in fp16-input GEMMs (the reference's GPU precision, reranker.py:91-93): scores stay within
+    fp16 rounding of the fp32 oracle and the fp32 GPU path; the default path is untouched."""
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    w = random_weights(cfg, 5)
+    w["head_out_w"] = (w["head_out_w"] * 20).astype(np.float32)
+    rng = np.random.default_rng(5)
+    seqs = _seqs(rng, rng.integers(24, 65, size=64), cfg.vocab_size)  # 64 pairs > 1024 tokens: the big-M path
+    types = [[0] * 10 + [1] * (len(s) - 10) for s in seqs]
+    want = obert.classify(cfg, w, seqs, types, sigmoid=False)
+    f32 = BertModel(cfg, w)
+    got32 = f32.classify(seqs, types, sigmoid=False)
+    f32.close()
+    cfg16 = _small(BertConfig.ms_marco_minilm_l6())
+    cfg16.gemm_dtype = "f16"
+    f16 = BertModel(cfg16, w)
+    got16 = f16.classify(seqs, types, sigmoid=False)
+    probs16 = f16.classify(seqs, types)
+    f16.close()
+    np.testing.assert_allclose(got32, want, atol=1e-4, rtol=1e-4)
+    assert np.abs(got16 - want).max() < 3e-2 * max(1.0, np.abs(want).max())  # fp16 inputs: ~1e-3 relative per GEMM
+    assert np.abs(got16 - want).max() > 0  # and it really is a different arithmetic
+    np.testing.assert_allclose(probs16, obert.classify(cfg, w, seqs, types), atol=5e-3)
