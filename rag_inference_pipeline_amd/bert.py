@@ -13,6 +13,7 @@ Hugging Face BERT / RoBERTa / XLM-RoBERTa state dicts into it.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import json
 import os
 from dataclasses import dataclass, field
@@ -209,10 +210,11 @@ def pack_sequences(seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[i
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
     cu = np.zeros(len(seqs) + 1, dtype=np.int32)
     np.cumsum(lens, out=cu[1:])
-    ids = np.fromiter((t for s in seqs for t in s), dtype=np.int32, count=int(cu[-1]))
+    total = int(cu[-1])
+    ids = np.fromiter(itertools.chain.from_iterable(seqs), dtype=np.int32, count=total)
     types = None
     if type_seqs is not None:
-        types = np.fromiter((t for s in type_seqs for t in s), dtype=np.int32, count=int(cu[-1]))
+        types = np.fromiter(itertools.chain.from_iterable(type_seqs), dtype=np.int32, count=total)
     return ids, types, cu
 
 

@@ -46,10 +46,18 @@ class HashTokenizer:
         self.roberta = roberta
         self.cls_id, self.sep_id, self.pad_id = (0, 2, 1) if roberta else (101, 102, 0)
         self._first = 1000 if vocab_size > 2000 else 8
+        self._memo: dict[str, int] = {}
+
+    def _piece_id(self, piece: str) -> int:
+        pid = self._memo.get(piece)
+        if pid is None:
+            pid = self._first + zlib.crc32(piece.encode("utf-8")) % (self.vocab_size - self._first)
+            if len(self._memo) < 200_000:
+                self._memo[piece] = pid
+        return pid
 
     def _ids(self, text: str) -> list[int]:
-        span = self.vocab_size - self._first
-        return [self._first + zlib.crc32(p.encode("utf-8")) % span for p in self._piece.findall(text.lower())]
+        return [self._piece_id(p) for p in self._piece.findall(text.lower())]
 
     def encode_batch(self, texts: Sequence[str], max_length: int) -> tuple[list[list[int]], list[list[int]]]:
         ids = [[self.cls_id] + self._ids(t)[: max(0, max_length - 2)] + [self.sep_id] for t in texts]
@@ -59,8 +67,12 @@ class HashTokenizer:
                      ) -> tuple[list[list[int]], list[list[int]]]:
         out_ids, out_types = [], []
         n_special = 4 if self.roberta else 3
+        memo: dict[str, list[int]] = {}  # a rerank batch repeats each query once per document
         for a, b in zip(first, second):
-            ia, ib = self._ids(a), self._ids(b)
+            ia = memo.get(a)
+            if ia is None:
+                ia = memo[a] = self._ids(a)
+            ia, ib = list(ia), self._ids(b)
             while len(ia) + len(ib) + n_special > max_length and (ia or ib):  # longest_first truncation
                 if len(ib) >= len(ia):
                     ib.pop()

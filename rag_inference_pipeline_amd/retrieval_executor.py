@@ -139,9 +139,9 @@ class RetrievalExecutor:
 
     @staticmethod
     def _to_retrieval_docs(docs: list[StoreDocument], scores: list[float]) -> list[RetrievalDocument]:
-        return [RetrievalDocument(doc_id=d.doc_id, title=d.title, content=d.content,
-                                  category=d.category or "", score=float(s))
-                for d, s in zip(docs, scores)]  # no strict check, as the reference
+        return [RetrievalDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
+                                                  category=d.category or "", score=float(s))
+                for d, s in zip(docs, scores)]  # no strict length check, as the reference
 
     def _process_batch_sync(self, batch: Batch[RetrievalResponseItem]) -> list[RetrievalResponseItem]:
         if not self.registry.get("faiss_store"):
@@ -153,11 +153,11 @@ class RetrievalExecutor:
         per_request = [self._to_retrieval_docs(docs, scores)
                        for docs, scores in zip(documents_batch, distances_batch)]
         if reranker:
-            inputs = [[Document(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category)
-                       for d in docs] for docs in per_request]
+            inputs = [[Document.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
+                                                category=d.category) for d in docs] for docs in per_request]
             reranked = reranker.rerank_batch([req.query for req in batch.requests], inputs)
-            per_request = [[RetrievalDocument(doc_id=d.doc_id, title=d.title, content=d.content,
-                                              category=d.category, score=d.score) for d in docs]
+            per_request = [[RetrievalDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
+                                                              category=d.category, score=d.score) for d in docs]
                            for docs in reranked]
         return [RetrievalResponseItem(request_id=req.request_id, docs=docs, compressed_docs=None)
                 for req, docs in zip(batch.requests, per_request)]

@@ -1,0 +1,83 @@
+"""Whole retrieval-node batch (BASELINE configs[1] / [2]) through the Python components and the
+executor: text queries -> encoder -> 1M x 384 scan + top-k -> SQLite document fetch -> (cross-encoder).
+Reports per-stage wall time from the executor's stage timers and batches/s; this is where host-side
+costs (tokenisation, document objects) show up next to the kernels.
+
+    python scripts/bench_pipeline.py [--rows 1000000] [--rerank] [--k 100] [--batches 10]
+"""
+import argparse, os, sqlite3, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, ".")
+from rag_inference_pipeline_amd.batch_scheduler import Batch
+from rag_inference_pipeline_amd.component_registry import ComponentRegistry
+from rag_inference_pipeline_amd.components.document_store import DocumentStore
+from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+from rag_inference_pipeline_amd.components.reranker import Reranker
+from rag_inference_pipeline_amd.config import PipelineSettings
+from rag_inference_pipeline_amd.flat_index import FlatIndex
+from rag_inference_pipeline_amd.retrieval_executor import RetrievalExecutor
+from rag_inference_pipeline_amd.schemas import PendingRequest
+from rag_inference_pipeline_amd.telemetry import stage_timers
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=1_000_000)
+ap.add_argument("--rerank", action="store_true")
+ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--batches", type=int, default=10)
+ap.add_argument("--dtype", default="f32")
+a = ap.parse_args()
+
+WORDS = ("retrieval augmented generation pipeline vector index query document embedding transformer attention "
+         "gpu memory bandwidth kernel matrix latency throughput batch scheduler cache shard merge score").split()
+rng = np.random.default_rng(0)
+tmp = tempfile.mkdtemp()
+os.makedirs(os.path.join(tmp, "documents"))
+con = sqlite3.connect(os.path.join(tmp, "documents", "documents.db"))
+con.execute("CREATE TABLE documents (doc_id INTEGER PRIMARY KEY, title TEXT, content TEXT, category TEXT)")
+t0 = time.time()
+CH = 100_000
+for lo in range(0, a.rows, CH):
+    n = min(CH, a.rows - lo)
+    words = rng.choice(WORDS, size=(n, 25))  # ~25 words per synthetic doc (reference scripts/create_test_docs.py:47)
+    con.executemany("INSERT INTO documents VALUES (?,?,?,?)",
+                    ((lo + i, f"Document {lo + i}", " ".join(words[i]), "general") for i in range(n)))
+con.commit(); con.close()
+print(f"sqlite: {a.rows} docs in {time.time() - t0:.1f}s", flush=True)
+
+settings = PipelineSettings(DOCUMENTS_DIR=os.path.join(tmp, "documents"), DOCUMENTS_PAYLOAD_MODE="full",
+                            DISABLE_CACHE_FOR_PROFILING="true", faiss_dim=384, retrieval_k=a.k,
+                            embedding_model_name="synthetic:all-MiniLM-L6-v2", reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2",
+                            RAG_AMD_RERANKER_DTYPE=a.dtype)
+
+
+class SyntheticStore:  # FAISSStore surface over a synthetic corpus (no 1.5 GB file round trip)
+    is_loaded = True
+    def __init__(self, n, d):
+        self.index = FlatIndex(d); self.index.add_synthetic(n, 1234)
+    def search(self, emb, k):
+        return self.index.search(emb.astype("float32"), k)
+
+reg = ComponentRegistry()
+emb = EmbeddingGenerator(settings); reg.register("embedding_generator", emb, emb.load)
+reg.register("faiss_store", SyntheticStore(a.rows, 384))
+reg.register("document_store", DocumentStore(settings))
+if a.rerank:
+    rr = Reranker(settings); reg.register("reranker", rr, rr.load)
+ex = RetrievalExecutor(reg, settings)
+queries = [" ".join(rng.choice(WORDS, size=int(rng.integers(6, 16)))) + "?" for _ in range(32)]
+mk = lambda: Batch(1, [PendingRequest(request_id=f"r{i}", query=q, timestamp=time.time()) for i, q in enumerate(queries)])
+ex._process_batch_sync(mk())  # warm
+stage_timers.reset()
+extra = {"tokenize_pairs": 0.0}
+t0 = time.perf_counter()
+for _ in range(a.batches):
+    items = ex._process_batch_sync(mk())
+el = time.perf_counter() - t0
+print(f"rows={a.rows} k={a.k} rerank={a.rerank} dtype={a.dtype}: {el / a.batches * 1e3:.2f} ms/batch  {32 * a.batches / el:.0f} queries/s")
+snap = stage_timers.snapshot()
+acc = 0.0
+for s, v in snap.items():
+    print(f"   {s:28s} {v['seconds'] / a.batches * 1e3:8.2f} ms/batch")
+    acc += v["seconds"]
+print(f"   {'(rest: rerank + objects)':28s} {(el - acc) / a.batches * 1e3:8.2f} ms/batch")
+assert len(items) == 32 and len(items[0].docs) == a.k
