@@ -312,6 +312,18 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
     if (h->prof) {
         HIP_TRY(hipEventRecord(e1, st));
         h->prof_events.emplace_back(e0, e1);
+        if (h->prof_events.size() >= 4096) {  // nobody is collecting: fold what has finished into the totals
+            for (auto& ev : h->prof_events) {
+                float ms = 0.f;
+                if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                    h->prof_ms += ms;
+                    h->prof_launches += 1;
+                }
+                (void)hipEventDestroy(ev.first);
+                (void)hipEventDestroy(ev.second);
+            }
+            h->prof_events.clear();
+        }
     }
 
     // merge: per query the top-k of the grid sorted lists, decoded into (score, id)
