@@ -138,6 +138,43 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedParams p) {
     ln_store(v, lane, p.H, p.eps, p.ln_g, p.ln_b, p.out + (size_t)t * p.H);
 }
 
+// Epilogue shared by the GEMM kernels.  The MFMAs are issued as D = W_tile · A_tileᵀ, so the LANE is the
+// token row and registers 4g..4g+3 are four CONSECUTIVE output features: bias, residual and the result
+// move as float4 (4 wide stores per 32x32 tile instead of 16 scalar ones; the scalar epilogue was a
+// fixed cost worth ~6 K-tiles per output tile at K = 384).
+__device__ __forceinline__ void store_tile_rows(const f32x16& acc, int m, int n_base, int h, int M, int N,
+                                                const float* bias, const float* R, int ldr, float* C, int ldc,
+                                                int act, bool plain) {
+    if (m >= M) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n_base + 8 * g + 4 * h;
+        if (n >= N) continue;
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (n + 3 < N) {
+            if (!plain) {
+                if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+                if (R) v += *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + n);
+            }
+            *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e < N) {
+                    float x = v[e];
+                    if (!plain) {
+                        x = apply_act(x + (bias ? bias[n + e] : 0.f), act);
+                        if (R) x += R[(size_t)m * ldr + n + e];
+                    }
+                    C[(size_t)m * ldc + n + e] = x;
+                }
+            }
+        }
+    }
+}
+
 // ---- GEMM: C[M][N] = A[M][K] · W[N][K]ᵀ (+ bias[N]) (+ R[M][N]) (act) -------------------------------------
 // (64·TM) x (64·TN) x 32 tiles, 4 waves (2 x 2), each wave TM x TN MFMA tiles of 32 x 32:
 //   TM = TN = 2: 128 x 128 tiles for big M (cross-encoder: M = all tokens of all pairs);
@@ -238,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[b][t], af[a][t], acc[a][b], 0, 0, 0);
         }
     };
     if constexpr (TM * TN == 1) {
@@ -281,29 +318,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
         }
     }
 
-    // epilogue: lane (r, h) holds column n = .. + r, rows (i&3) + 8(i>>2) + 4h of each 32x32 tile
+    // epilogue: lane r is token row .. + r, registers hold 16 of the 32 output features of each tile
     float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * 32 * TN + b * 32 + r;
-        if (n >= p.N) continue;
-        const float bias = (!split && p.bias) ? p.bias[n] : 0.f;
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 32 * TM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < p.M) {
-                    float v = acc[a][b][i];
-                    if (!split) {
-                        v = apply_act(v + bias, p.act);
-                        if (p.R) v += p.R[(size_t)m * p.ldr + n];
-                    }
-                    Cz[(size_t)m * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+        for (int b = 0; b < TN; ++b)
+            store_tile_rows(acc[a][b], m0 + wm * 32 * TM + a * 32 + r, n0 + wn * 32 * TN + b * 32, h, p.M, p.N,
+                            p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);
 }
 
 // Half-precision-input GEMM (opt-in, big M only): A is fp32 in memory and rounded to fp16 while it is
@@ -397,27 +419,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p)
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[b], af[a], acc[a][b], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wn * 64 + b * 32 + r;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = m0 + wm * 64 + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (m < p.M) {
-                    float v = apply_act(acc[a][b][i] + bias, p.act);
-                    if (p.R) v += p.R[(size_t)m * p.ldr + n];
-                    p.C[(size_t)m * p.ldc + n] = v;
-                }
-            }
-        }
-    }
+        for (int b = 0; b < 2; ++b)
+            store_tile_rows(acc[a][b], m0 + wm * 64 + a * 32 + r, n0 + wn * 64 + b * 32, h, p.M, p.N, p.bias, p.R,
+                            p.ldr, p.C, p.ldc, p.act, false);
 }
 
 // Small-M GEMM: 64 x 64 x 64 tiles, EIGHT waves.  Waves 0-3 (2 x 2 over the tile) multiply columns 0-31 of
@@ -480,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm_nt_small_kernel(const GemmParams p) 
             const f32x4 af = *reinterpret_cast<const f32x4*>(As + kg * 8);
             const f32x4 bf = *reinterpret_cast<const f32x4*>(Ws + kg * 8);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[t], acc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t], af[t], acc, 0, 0, 0);
         }
     };
     load_tile(ra0, rw0, 0);
@@ -518,21 +528,7 @@ __global__ __launch_bounds__(512) void gemm_nt_small_kernel(const GemmParams p) 
     for (int i = 0; i < 16; ++i) acc[i] += xch[((wave & 3) * 16 + i) * 64 + lane];
 
     float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
-    const int n = n0 + wn * 32 + r;
-    if (n >= p.N) return;
-    const float bias = (!split && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int m = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (m < p.M) {
-            float v = acc[i];
-            if (!split) {
-                v = apply_act(v + bias, p.act);
-                if (p.R) v += p.R[(size_t)m * p.ldr + n];
-            }
-            Cz[(size_t)m * p.ldc + n] = v;
-        }
-    }
+    store_tile_rows(acc, m0 + wm * 32 + r, n0 + wn * 32, h, p.M, p.N, p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);
 }
 
 // y[t] = LayerNorm( sum_z part[z][t] + bias + R[t] ): reduces split-K slabs in slab order (a fixed
