@@ -103,3 +103,19 @@ def test_faiss_store_error_contract_without_gpu(tmp_path):
     with pytest.raises(RuntimeError, match="not loaded"):
         store.search(np.zeros((1, 768), np.float32), 1)
     store.unload()  # no-op when not loaded
+
+
+def test_product_package_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: nothing under rag_inference_pipeline_amd/ may import it, and
+    nothing there may read the reference checkout at run time."""
+    import pathlib
+    pkg = pathlib.Path(__file__).resolve().parent.parent / "rag_inference_pipeline_amd"
+    offenders = []
+    for path in pkg.rglob("*.py"):
+        text = path.read_text()
+        if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "/root/reference" in text:
+            offenders.append(str(path))
+    for path in list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")):
+        if "/root/reference" in path.read_text():
+            offenders.append(str(path))
+    assert not offenders, offenders
