@@ -151,13 +151,14 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
 
     // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
+    const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
     for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
         const int s = idx >> 6, l = idx & 63;
         const int qrow = l & 31, col = p.col0 + 8 * s + 4 * (l >> 5);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (qrow < p.nq) {
             const float* src = p.Q + (size_t)qrow * p.d + col;
-            if ((p.d & 3) == 0 && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
+            if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
                 v = *reinterpret_cast<const f32x4*>(src);
             } else {
 #pragma unroll
