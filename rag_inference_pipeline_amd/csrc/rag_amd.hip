@@ -23,25 +23,8 @@ thread_local char g_err[512] = "";
 
 #define fail ragc_fail
 
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(e_ == hipErrorOutOfMemory ? RAG_ERR_OOM : RAG_ERR_HIP, "%s: %s", #expr, \
-                        hipGetErrorString(e_));                                                \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
+#define HIP_TRY RAGC_HIP_TRY
+using DeviceGuard = RagcDeviceGuard;
 
 template <typename T>
 int dev_alloc(T** p, size_t count) {
