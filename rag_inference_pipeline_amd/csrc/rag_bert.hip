@@ -142,8 +142,21 @@ int launch_gemm_ln(const float* A, int lda, const float* W, const _Float16* W16,
     if (M <= 0) return RAG_OK;
     int splits = 1;
     if (M <= 1024) {
-        const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
-        splits = std::max(1, std::min({kMaxSplits, (n_cus + tiles - 1) / tiles, K / (4 * ragb::GBK)}));
+        // One wave multiplies one 32x32 output tile over its K range, and the chip has 4 * n_cus SIMDs:
+        // pick the split that minimises (rounds of wave-tiles) x (K per split), e.g. 336 tiles at
+        // K = 3072 are one round of K = 1024 with 3 splits but two rounds of K = 768 with 4.
+        const long long wave_tiles = (long long)((N + 31) / 32) * ((M + 31) / 32);
+        const long long simds = 4LL * n_cus;
+        long long best = -1;
+        for (int sp = 1; sp <= kMaxSplits; ++sp) {
+            if (K % (ragb::SBK * sp)) continue;
+            const long long rounds = (wave_tiles * sp + simds - 1) / simds;
+            const long long cost = rounds * (K / sp) + 16 * sp;  // + a little per slab for the reduce pass
+            if (best < 0 || cost < best) {
+                best = cost;
+                splits = sp;
+            }
+        }
     }
     if (splits == 1) {
         int rc = launch_gemm(A, lda, W, W16, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
