@@ -216,3 +216,30 @@ def test_retriever_with_rerank_profile_end_to_end(gpu_required, tmp_path):
         assert scores == sorted(scores, reverse=True) and len(item.docs) == 10
     asyncio.run(registry.stop_all())
     registry.unload_all()
+
+
+def test_build_index_tool_embeds_documents_and_round_trips(gpu_required, tmp_path):
+    """tools/build_index: documents -> encoder -> raw fp32 + sidecar -> FAISSStore; a document's own
+    text retrieves it first."""
+    import sqlite3
+    from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+    from rag_inference_pipeline_amd.tools.build_index import build_index
+    docs_dir = tmp_path / "documents"
+    docs_dir.mkdir()
+    texts = [f"document number {i} talks about topic {i % 7} and item {i * 13 % 101}" for i in range(300)]
+    con = sqlite3.connect(docs_dir / "documents.db")
+    con.execute("CREATE TABLE documents (doc_id INTEGER PRIMARY KEY, title TEXT, content TEXT, category TEXT)")
+    con.executemany("INSERT INTO documents VALUES (?,?,?,?)", [(i, f"t{i}", t, "c") for i, t in enumerate(texts)])
+    con.commit(); con.close()
+    out = tmp_path / "faiss_index.f32"
+    model = "synthetic:all-MiniLM-L6-v2:3"
+    n, d = build_index(str(docs_dir), model, str(out), batch_docs=128)
+    assert (n, d) == (300, 384) and out.stat().st_size == 300 * 384 * 4
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(out), faiss_dim=384))
+    store.load()
+    gen = EmbeddingGenerator(PipelineSettings(embedding_model_name=model, DISABLE_CACHE_FOR_PROFILING="true"))
+    gen.load()
+    probe = [5, 77, 299]
+    D, I = store.search(gen.encode([texts[i] for i in probe]), 3)
+    assert I[:, 0].tolist() == probe and np.allclose(D[:, 0], 1.0, atol=1e-5)
+    store.unload(); gen.unload()
