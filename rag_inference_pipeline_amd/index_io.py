@@ -14,8 +14,15 @@ three formats are read here, all yielding (rows float32 [n, d], metric):
     {"d": .., "ntotal": .., "metric": "ip" | "l2"} — the format bench/corpus tools write, suited
     to memory-mapping 30 GB shards.
 
-IVF files written by the reference's generator (scripts/create_test_docs.py:83-104, fourcc `IwFl`)
-are recognised and rejected with a clear message: this build searches exhaustively.
+  * FAISS `IndexIVFFlat` files (fourcc `IwFl`, what the reference's generator writes,
+    scripts/create_test_docs.py:83-104): the stored vectors are raw fp32 (IVFFlat keeps no residuals),
+    so the inverted lists are unpacked back into row order (row = stored id, which must be a
+    permutation of 0..ntotal-1) and searched exhaustively — the nprobe = nlist limit of that index.
+    The coarse quantizer is skipped.  Same caveat as above: layout restated from upstream, validated
+    structurally (list sizes must sum to ntotal, ids must be a permutation, file length must match)
+    and through this module's own writer.
+
+Other IVF/PQ variants (`IwPQ`, `IwQ4`, ...) hold compressed codes and are rejected with a message.
 """
 
 from __future__ import annotations
@@ -57,14 +64,146 @@ def write_flat_index(path: str | os.PathLike, rows: np.ndarray, metric: int = ME
         fh.write(rows.tobytes())
 
 
+class _Reader:
+    def __init__(self, path: Path) -> None:
+        self.buf = np.memmap(path, dtype=np.uint8, mode="r")
+        self.pos = 0
+        self.path = path
+
+    def take(self, fmt: str):
+        st = struct.Struct("<" + fmt)
+        if self.pos + st.size > self.buf.size:
+            raise ValueError(f"{self.path}: truncated file")
+        vals = st.unpack(self.buf[self.pos:self.pos + st.size].tobytes())
+        self.pos += st.size
+        return vals if len(vals) > 1 else vals[0]
+
+    def array(self, dtype, count: int) -> np.ndarray:
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        if count < 0 or self.pos + nbytes > self.buf.size:
+            raise ValueError(f"{self.path}: truncated file")
+        out = np.frombuffer(self.buf, dtype=dtype, count=int(count), offset=self.pos)
+        self.pos += nbytes
+        return out
+
+    def index_header(self) -> tuple[int, int, int]:
+        d, ntotal, _, _, _, metric_type = self.take("iqqqBi")
+        if metric_type > 1:
+            self.take("f")  # metric_arg
+        return d, ntotal, metric_type
+
+
+def _read_faiss_ivfflat(path: Path) -> tuple[np.ndarray, int]:
+    r = _Reader(path)
+    if r.array(np.uint8, 4).tobytes() != b"IwFl":
+        raise ValueError(f"{path}: not an IwFl file")
+    d, ntotal, metric_type = r.index_header()
+    if metric_type > 1 or d <= 0 or ntotal < 0:
+        raise ValueError(f"{path}: unsupported IVF header (d={d}, ntotal={ntotal}, metric_type={metric_type})")
+    nlist, _nprobe = r.take("QQ")
+    # coarse quantizer: a nested flat index holding nlist centroids — skipped
+    qcc = r.array(np.uint8, 4).tobytes()
+    if qcc not in _FLAT_FOURCC:
+        raise ValueError(f"{path}: coarse quantizer {qcc!r} is not a flat index")
+    qd, qn, _ = r.index_header()
+    r.array(np.float32, r.take("Q"))
+    if qd != d or qn != nlist:
+        raise ValueError(f"{path}: quantizer shape ({qn}, {qd}) does not match nlist={nlist}, d={d}")
+    # direct map: type byte, array, and (hashtable type only) a vector of (id, offset) pairs
+    dm_type = r.take("B")
+    r.array(np.int64, r.take("Q"))
+    if dm_type == 2:
+        r.array(np.int64, 2 * r.take("Q"))
+    # inverted lists
+    if r.array(np.uint8, 4).tobytes() != b"ilar":
+        raise ValueError(f"{path}: inverted lists are not an in-memory array ('ilar')")
+    il_nlist, code_size = r.take("QQ")
+    if il_nlist != nlist or code_size != 4 * d:
+        raise ValueError(f"{path}: list count / code size ({il_nlist}, {code_size}) do not describe raw fp32 vectors")
+    list_type = r.array(np.uint8, 4).tobytes()
+    raw = r.array(np.uint64, r.take("Q"))
+    sizes = np.zeros(nlist, dtype=np.int64)
+    if list_type == b"full":
+        if raw.size != nlist:
+            raise ValueError(f"{path}: 'full' size vector has {raw.size} entries, expected {nlist}")
+        sizes[:] = raw
+    elif list_type == b"sprs":
+        if raw.size % 2:
+            raise ValueError(f"{path}: 'sprs' size vector has odd length")
+        pairs = raw.reshape(-1, 2)
+        if pairs.size and pairs[:, 0].max() >= nlist:
+            raise ValueError(f"{path}: 'sprs' list number out of range")
+        sizes[pairs[:, 0].astype(np.int64)] = pairs[:, 1]
+    else:
+        raise ValueError(f"{path}: unknown list encoding {list_type!r}")
+    if int(sizes.sum()) != ntotal:
+        raise ValueError(f"{path}: inverted lists hold {int(sizes.sum())} vectors, header says {ntotal}")
+    rows = np.empty((ntotal, d), dtype=np.float32)
+    seen = np.zeros(ntotal, dtype=bool)
+    for n in sizes:
+        n = int(n)
+        if n == 0:
+            continue
+        codes = r.array(np.float32, n * d).reshape(n, d)
+        ids = r.array(np.int64, n)
+        if ids.min() < 0 or ids.max() >= ntotal or seen[ids].any():
+            raise ValueError(f"{path}: stored ids are not a permutation of 0..ntotal-1; row order cannot be restored")
+        seen[ids] = True
+        rows[ids] = codes
+    if not seen.all():
+        raise ValueError(f"{path}: some ids are missing from the inverted lists")
+    return rows, (METRIC_INNER_PRODUCT if metric_type == 0 else METRIC_L2)
+
+
+def write_ivfflat_index(path: str | os.PathLike, rows: np.ndarray, nlist: int, metric: int = METRIC_L2,
+                        seed: int = 0, sparse: bool = False) -> None:
+    """Write rows as a FAISS-layout IndexIVFFlat file (test helper: random centroids taken from the rows,
+    nearest-centroid assignment).  Mirrors what scripts/create_test_docs.py produces with faiss itself."""
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
+    n, d = rows.shape
+    rng = np.random.default_rng(seed)
+    cent = rows[rng.choice(n, size=min(nlist, n), replace=False)] if n else np.zeros((0, d), np.float32)
+    if cent.shape[0] < nlist:
+        cent = np.concatenate([cent, np.zeros((nlist - cent.shape[0], d), np.float32)])
+    assign = np.argmin(((rows[:, None, :] - cent[None, :min(nlist, 64), :]) ** 2).sum(-1), axis=1) if n else np.zeros(0, int)
+    metric_type = 0 if metric == METRIC_INNER_PRODUCT else 1
+    with open(path, "wb") as fh:
+        fh.write(b"IwFl")
+        fh.write(_HEADER.pack(d, n, 1 << 20, 1 << 20, 1, metric_type))
+        fh.write(struct.pack("<QQ", nlist, 1))
+        fh.write(b"IxF2")
+        fh.write(_HEADER.pack(d, nlist, 1 << 20, 1 << 20, 1, 1))
+        fh.write(struct.pack("<Q", nlist * d))
+        fh.write(cent.tobytes())
+        fh.write(struct.pack("<BQ", 0, 0))  # no direct map
+        fh.write(b"ilar")
+        fh.write(struct.pack("<QQ", nlist, 4 * d))
+        members = [np.nonzero(assign == l)[0].astype(np.int64) for l in range(nlist)]
+        if sparse:
+            pairs = [(l, len(m)) for l, m in enumerate(members) if len(m)]
+            fh.write(b"sprs")
+            fh.write(struct.pack("<Q", 2 * len(pairs)))
+            fh.write(np.array(pairs, dtype=np.uint64).tobytes())
+        else:
+            fh.write(b"full")
+            fh.write(struct.pack("<Q", nlist))
+            fh.write(np.array([len(m) for m in members], dtype=np.uint64).tobytes())
+        for m in members:
+            if len(m):
+                fh.write(rows[m].tobytes())
+                fh.write(m.tobytes())
+
+
 def _read_faiss_flat(path: Path, mmap: bool) -> tuple[np.ndarray, int]:
     size = path.stat().st_size
     with path.open("rb") as fh:
         fourcc = fh.read(4)
-        if fourcc in (b"IwFl", b"IwPQ", b"IwQ4", b"IvFl"):
+        if fourcc == b"IwFl":
+            return _read_faiss_ivfflat(path)
+        if fourcc in (b"IwPQ", b"IwQ4", b"IvFl", b"IwSq", b"IwSQ"):
             raise ValueError(
-                f"{path}: IVF index ({fourcc.decode()}); this build scans exhaustively — export the "
-                "vectors to a flat file (IxFI/IxF2, .npy, or raw fp32 + .json sidecar)")
+                f"{path}: compressed IVF index ({fourcc.decode()}); this build scans raw fp32 vectors — export "
+                "them to a flat file (IxFI/IxF2, .npy, or raw fp32 + .json sidecar)")
         if fourcc not in _FLAT_FOURCC:
             raise ValueError(f"{path}: unrecognised index fourcc {fourcc!r}")
         head = fh.read(_HEADER.size)

@@ -83,10 +83,23 @@ def test_index_file_formats_roundtrip(tmp_path):
     np.testing.assert_array_equal(rows, X)
     with pytest.raises(FileNotFoundError, match="FAISS index not found"):
         index_io.read_index_file(tmp_path / "missing.bin")
-    bad = tmp_path / "ivf.bin"
-    bad.write_bytes(b"IwFl" + b"\0" * 64)
-    with pytest.raises(ValueError, match="IVF index"):
+    bad = tmp_path / "ivfpq.bin"
+    bad.write_bytes(b"IwPQ" + b"\0" * 64)
+    with pytest.raises(ValueError, match="compressed IVF index"):
         index_io.read_index_file(bad)
+    # IndexIVFFlat (what the reference's generator writes): unpacked back into row order
+    for sparse in (False, True):
+        ivf = tmp_path / f"ivf{int(sparse)}.bin"
+        index_io.write_ivfflat_index(ivf, X, nlist=5 if not sparse else 200, metric=1, sparse=sparse)
+        rows, m = index_io.read_index_file(ivf)
+        assert m == 1
+        np.testing.assert_array_equal(rows, X)
+    broken = tmp_path / "ivf_broken.bin"
+    data = bytearray((tmp_path / "ivf0.bin").read_bytes())
+    data[-8:] = (10 ** 6).to_bytes(8, "little")  # last id out of range
+    broken.write_bytes(bytes(data))
+    with pytest.raises(ValueError, match="permutation"):
+        index_io.read_index_file(broken)
     trunc = tmp_path / "trunc.bin"
     trunc.write_bytes((tmp_path / "m0.faiss").read_bytes()[:-8])
     with pytest.raises(ValueError, match="truncated"):
