@@ -126,6 +126,28 @@ int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* scan_launche
 /* Largest k the fused scan+select kernel supports for (d, nq) on this build; 0 if d unsupported. */
 int32_t rag_index_max_k(int32_t d, int32_t nq);
 
+/* Two-stage exact search (optional, off by default).  With RAG_SCREEN_FP16 the index keeps a scaled
+ * fp16 copy of the corpus beside the fp32 rows (+50 % memory).  A search of k <= 100 then (1) scans
+ * the copy — half the bytes of the fp32 scan — keeping every row whose approximate score lies within
+ * a worst-case error band of the running k-th best, (2) recomputes the canonical fp32 score of those
+ * candidates and ranks them, (3) checks per query a certificate that no row outside the candidate
+ * list can reach the k-th exact score.  Queries that pass return exactly what the one-pass fp32
+ * search returns (same ids, bit-identical scores); queries that fail are re-run through the fp32
+ * scan on the device, so results never depend on the mode.  Applies to d <= 1024 with finite corpus
+ * values of ordinary magnitude; otherwise the index reports RAG_SCREEN_INACTIVE and searches use the
+ * fp32 scan.  (No counterpart in the reference: faiss IndexFlat has one code path.) */
+#define RAG_SCREEN_OFF 0
+#define RAG_SCREEN_FP16 1
+#define RAG_SCREEN_INACTIVE 2   /* requested, but the corpus is outside what the error bound covers */
+int rag_index_set_screening(rag_index* h, int32_t mode);
+int32_t rag_index_screening(const rag_index* h);
+
+/* Counters of the two-stage search since the last reset: queries answered, queries that fell back
+ * to the fp32 scan, and the largest observed |approximate - exact| / (error bound) over all verified
+ * candidates (must stay below 1; typically ~0.03). */
+int rag_index_screen_stats(rag_index* h, int64_t* queries, int64_t* fallbacks, double* max_err_ratio,
+                           int32_t reset);
+
 /* Merge per-shard top-k lists (the step after the RCCL all-gather):
  *   scores_dev / ids_dev : n_shards x nq x k, each list sorted as rag_index_search returns it
  *   out                  : nq x k, same ordering rule (score, then ascending id)

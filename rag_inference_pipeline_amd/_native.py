@@ -115,6 +115,9 @@ def _declare(lib: C.CDLL) -> None:
         "rag_index_profile_enable": (C.c_int, [vp, C.c_int32]),
         "rag_index_profile": (C.c_int, [vp, C.POINTER(C.c_double), i64p, C.c_int32]),
         "rag_index_max_k": (C.c_int32, [C.c_int32, C.c_int32]),
+        "rag_index_set_screening": (C.c_int, [vp, C.c_int32]),
+        "rag_index_screening": (C.c_int32, [vp]),
+        "rag_index_screen_stats": (C.c_int, [vp, i64p, i64p, C.POINTER(C.c_double), C.c_int32]),
         "rag_merge_topk_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                             vp, vp, vp, vp, vp]),
         "rag_merge_topk_packed_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

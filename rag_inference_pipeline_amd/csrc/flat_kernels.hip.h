@@ -28,6 +28,7 @@ namespace ragk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned long long u64;
 
 constexpr int kQT = 32;        // queries per scan pass (MFMA N)
@@ -105,6 +106,21 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&key)[NQ][E], int lane) {
 
 // ---- K1: scan + select ----------------------------------------------------------------------
 
+// One ring slot (32 bytes of a row across the two lane halves) times the matching query fragment.
+template <int P>
+__device__ __forceinline__ f32x16 scan_step(const f32x4 x, const f32x4 q, f32x16 acc) {
+    if constexpr (P == 1) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, q), acc,
+                                                      0, 0, 0);
+    } else {
+        acc = RAGK_MFMA(x[0], q[0], acc);
+        acc = RAGK_MFMA(x[1], q[1], acc);
+        acc = RAGK_MFMA(x[2], q[2], acc);
+        acc = RAGK_MFMA(x[3], q[3], acc);
+        return acc;
+    }
+}
+
 struct ScanParams {
     const float* X;        // corpus, row-major, row_stride floats per row (zero padded to d8)
     const float* xnorm;    // canonical squared norms (L2 metric only)
@@ -124,17 +140,31 @@ struct ScanParams {
     int k;
     int n_tiles;           // ceil(n_rows / 32)
     int n_iters;           // tiles per wave
+    const uint32_t* enable;  // null, or a device word: 0 turns the whole launch into a no-op (fallback path)
+    // screening pass (P == 1) only
+    int kout;              // keys emitted per (query, workgroup), >= k
+    const float* qscale;   // [kQT] power-of-two scale applied to a query before it is rounded to fp16
+    const float* unscale;  // [kQT] 1 / (qscale * corpus scale)
+    const float* margin;   // [kQT] width of the band kept below the running k-th best approximate score
+    uint32_t* lossy;       // [kQT] set when a workgroup could not hold a query's band (the certificate is void)
 };
 
-// LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32]
+// LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32][margin 32 f32]
 __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = columns held in LDS (one chunk)
-    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16;
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4;
 }
 
 // NW = waves per workgroup (NW/4 per SIMD), E = buffer capacity / 64, D = register ring depth
-// (steps of 8 columns in flight per wave), L2 = metric.
-template <int NW, int E, int D, bool L2>
+// (steps of 32 bytes per row in flight per wave), L2 = metric.
+// P = 0: the exact pass.  X is fp32, one step = 8 columns = 4 x v_mfma_f32_32x32x2_f32.
+// P = 1: the screening pass of the two-stage search.  X is the scaled fp16 copy of the corpus, one
+//        step = 16 columns = 1 x v_mfma_f32_32x32x16_f16 (same 32 bytes per row per step, so the
+//        addressing is shared: the host passes row_stride and dc8 in 4-byte units).  Scores are
+//        approximate; instead of the best k the buffers keep every row within `margin` of the
+//        running k-th best, which is what makes the exact second stage a proof rather than a guess.
+template <int NW, int E, int D, bool L2, int P>
 __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) {
+    if (p.enable && *p.enable == 0) return;  // launch-uniform
     constexpr int C = 64 * E;
     constexpr int kScanWaves = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,30 +179,55 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     uint32_t* cnt = reinterpret_cast<uint32_t*>(keys + (size_t)kQT * C);
     float* thr = reinterpret_cast<float*>(cnt + kQT);
     uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
+    float* mrg = reinterpret_cast<float*>(flag + 4);
 
-    // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
-    const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
-    for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
-        const int s = idx >> 6, l = idx & 63;
-        const int qrow = l & 31, col = p.col0 + 8 * s + 4 * (l >> 5);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (qrow < p.nq) {
-            const float* src = p.Q + (size_t)qrow * p.d + col;
-            if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
-                v = *reinterpret_cast<const f32x4*>(src);
-            } else {
+    if (P == 1) {
+        // ---- prologue: queries -> fp16 B fragments.  Fragment (s, l) = Q[l&31][16s + 8(l>>5) .. +7] * qscale.
+        for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
+            const int s = idx >> 6, l = idx & 63;
+            const int qrow = l & 31, col = 16 * s + 8 * (l >> 5);
+            f16x8 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (col + j < p.d) v[j] = src[j];
+            for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+            if (qrow < p.nq) {
+                const float* src = p.Q + (size_t)qrow * p.d + col;
+                const float qs = p.qscale[qrow];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (col + j < p.d) v[j] = (_Float16)(src[j] * qs);
             }
+            qf[idx] = __builtin_bit_cast(f32x4, v);
         }
-        qf[idx] = v;
+    } else {
+        // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
+        const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
+        for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
+            const int s = idx >> 6, l = idx & 63;
+            const int qrow = l & 31, col = p.col0 + 8 * s + 4 * (l >> 5);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qrow < p.nq) {
+                const float* src = p.Q + (size_t)qrow * p.d + col;
+                if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
+                    v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (col + j < p.d) v[j] = src[j];
+                }
+            }
+            qf[idx] = v;
+        }
     }
     if (tid < kQT) {
         cnt[tid] = 0;
         // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
         // they never enter the slow path (left at -inf they tie forever and double the scan time)
         thr[tid] = tid < p.nq ? -__builtin_inff() : __builtin_inff();
+        if (P == 1) {
+            mrg[tid] = tid < p.nq ? p.margin[tid] : 0.f;
+            // a query the prep kernel ruled out (non-finite, out of range) is answered by the fallback
+            if (tid < p.nq && p.lossy[tid]) thr[tid] = __builtin_inff();
+        }
     }
     if (tid < 4) flag[tid] = 0;
     __syncthreads();
@@ -232,13 +287,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                 for (int j = 0; j < G; ++j) {
                     const int i = g + j;
                     const f32x4 qn = qs[i * 64];
-                    acc = RAGK_MFMA(xb[i][0], qcur[0], acc);
-                    acc = RAGK_MFMA(xb[i][1], qcur[1], acc);
-                    acc = RAGK_MFMA(xb[i][2], qcur[2], acc);
-                    acc = RAGK_MFMA(xb[i][3], qcur[3], acc);
+                    acc = scan_step<P>(xb[i], qcur, acc);
                     qcur = qn;
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // next query fragment (DS read)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // 4 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x008, P == 1 ? 1 : 4, 0);  // this step's MFMA
                 }
 #pragma unroll
                 for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(src + 8 * (g + j));
@@ -256,13 +308,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                     const int i = g + j;
                     // the fragment after the last step is never used; stay inside the Q image
                     const f32x4 qn = qs[(i + 1 < D ? i : -1 - s0) * 64];
-                    acc = RAGK_MFMA(xb[i][0], qcur[0], acc);
-                    acc = RAGK_MFMA(xb[i][1], qcur[1], acc);
-                    acc = RAGK_MFMA(xb[i][2], qcur[2], acc);
-                    acc = RAGK_MFMA(xb[i][3], qcur[3], acc);
+                    acc = scan_step<P>(xb[i], qcur, acc);
                     qcur = qn;
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, P == 1 ? 1 : 4, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(pn + 8 * (g + j));
@@ -284,6 +333,11 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         // ---- ranking scores.  Lane (r, h): query r, tile rows (i&3) + 8(i>>2) + 4h.
         const long long row0 = (long long)tile * kTileRows;
         float sc[16];
+        if (P == 1) {  // undo the power-of-two scales (exact)
+            const float uns = p.unscale[r];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= uns;
+        }
         if (L2) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -355,7 +409,44 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 #pragma unroll
                 for (int j = 0; j < NQW; ++j) {
                     const int q = wave + kScanWaves * j;
-                    if (q < kQT && nn[j] > 0) {  // sorting a short buffer is harmless: cnt and thr stay consistent
+                    if (P == 1) {
+                        // keep the band: every key whose score is within mrg[q] of the k-th best so far
+                        if (q < kQT && nn[j] > 0) {  // wave-uniform
+                            u64 kth = 0ull;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const u64 c = ((u64)__shfl((uint32_t)(kk[j][e] >> 32), (p.k - 1) & 63, 64)) << 32;
+                                if (e == ((p.k - 1) >> 6)) kth = c;
+                            }
+                            const bool full = nn[j] >= (uint32_t)p.k;
+                            const float kscore = unord32((uint32_t)(kth >> 32));
+                            float tnew = full ? kscore - mrg[q] : -__builtin_inff();
+                            uint32_t keep = 0;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const uint32_t idx = e * 64 + lane;
+                                const bool kp = idx < nn[j] && unord32((uint32_t)(kk[j][e] >> 32)) >= tnew;
+                                keep += (uint32_t)__popcll(__ballot(kp));
+                            }
+                            if (keep > (uint32_t)(C - 16)) {  // the band does not fit: give it up for this query
+                                if (lane == 0) {
+                                    mrg[q] = 0.f;
+                                    atomicOr(&p.lossy[q], 1u);
+                                }
+                                tnew = kscore;  // keep > C - 16 >= k implies full
+                                keep = (uint32_t)p.k;
+                            }
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const uint32_t idx = e * 64 + lane;
+                                if (idx < keep) keys[(size_t)q * C + idx] = kk[j][e];
+                            }
+                            if (lane == 0) {
+                                thr[q] = tnew;
+                                cnt[q] = keep;
+                            }
+                        }
+                    } else if (q < kQT && nn[j] > 0) {  // sorting a short buffer is harmless: cnt and thr stay consistent
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             const int idx = e * 64 + lane;
@@ -411,11 +502,15 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         for (int j = 0; j < NQW; ++j) {
             const int q = wave + kScanWaves * j;
             if (q < kQT) {
-                u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * p.k;
+                const int kout = P == 1 ? p.kout : p.k;
+                u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * kout;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     const int idx = e * 64 + lane;
-                    if (idx < p.k) out[idx] = kk[j][e];
+                    if (idx < kout) out[idx] = kk[j][e];
+                }
+                if (P == 1) {  // kout may exceed the buffer: pad the list with empty keys
+                    for (int idx = C + lane; idx < kout; idx += 64) out[idx] = 0ull;
                 }
             }
         }
@@ -463,32 +558,71 @@ struct MergeOut {
     long long id_offset;
     int metric;          // 0 IP, 1 L2
     int from_shards;     // keys carry (-distance, id) of already finished results
+    const uint32_t* qmask;  // null, or [nq] words: only queries with a non-zero word are written (fallback path)
 };
 
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = umax64(v, shfl_xor_u64(v, m));
-    return v;
+// Wave-wide 64-bit max on the DPP cross-lane paths (quad permutes, row mirrors, row broadcasts): a
+// few cycles per step where a ds_bpermute shuffle costs an LDS round trip — the tournament below runs
+// one of these per round, and with shuffles that was most of a round's 0.8 us.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return ((u64)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {  // the result is wave-uniform
+    v = umax64(v, dpp_u64<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+    v = umax64(v, dpp_u64<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+    v = umax64(v, dpp_u64<0x141, 0xF>(v));  // row_half_mirror
+    v = umax64(v, dpp_u64<0x140, 0xF>(v));  // row_mirror: every lane of a row holds the row's max
+    v = umax64(v, dpp_u64<0x142, 0xA>(v));  // row_bcast15 into rows 1 and 3
+    v = umax64(v, dpp_u64<0x143, 0xC>(v));  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's max
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    return ((u64)hi << 32) | lo;
 }
 
-template <class Src>
+// The first `look` keys of every list are staged in LDS up front (coalesced), so a round never waits
+// for global memory: the winner's list advances with one LDS read.  (With the look-ahead in
+// registers, loaded when a list advanced, the compiler put the load's full latency on every round:
+// 0.7 us per round, 74 us for k = 100.)  Lists that contribute more than `look` keys read on from
+// global memory.
+__host__ __device__ inline int merge_look(int n_lists, int list_len, int k) {
+    const int nl = n_lists > 0 ? n_lists : 1;
+    const int fit = 6144 / nl;                 // 48 KiB of keys
+    int want = 2 * ((k + nl - 1) / nl) + 4;    // a list's expected share of the k winners, with slack
+    if (want > fit) want = fit < 2 ? 2 : fit;
+    return want < list_len ? want : list_len;
+}
+
+// OWN = lists per thread (n_lists <= 256 * OWN): a round is a serial chain of wave-wide instructions,
+// so every compare that a smaller OWN removes shortens all k rounds.
+template <class Src, int OWN>
 __global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, const int n_lists, const int k,
-                                                               const MergeOut out) {
+                                                               const int look, const MergeOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* ahead = reinterpret_cast<u64*>(smem);  // [n_lists][look]
     __shared__ u64 wmax[2][4];
     const int q = blockIdx.x, tid = threadIdx.x;
-    u64 head[kMergeMaxOwned], next[kMergeMaxOwned];
-    int pos[kMergeMaxOwned];
+    if (out.qmask && out.qmask[q] == 0) return;  // workgroup-uniform
+    for (int idx = tid; idx < n_lists * look; idx += 256) {
+        const int l = idx / look, p = idx - l * look;
+        ahead[idx] = src.get(q, l, p);
+    }
+    __syncthreads();
+    u64 head[OWN];
+    int pos[OWN];
 #pragma unroll
-    for (int j = 0; j < kMergeMaxOwned; ++j) {
+    for (int j = 0; j < OWN; ++j) {
         const int l = tid + 256 * j;
         pos[j] = 0;
-        head[j] = (l < n_lists && k > 0) ? src.get(q, l, 0) : 0ull;
-        next[j] = (l < n_lists && k > 1) ? src.get(q, l, 1) : 0ull;  // one key of look-ahead per list
+        head[j] = (l < n_lists && k > 0) ? ahead[(size_t)l * look] : 0ull;
     }
     for (int round = 0; round < k; ++round) {
         u64 best = head[0];
 #pragma unroll
-        for (int j = 1; j < kMergeMaxOwned; ++j) best = umax64(best, head[j]);
+        for (int j = 1; j < OWN; ++j) best = umax64(best, head[j]);
         const u64 wm = wave_max_u64(best);
         if ((tid & 63) == 0) wmax[round & 1][tid >> 6] = wm;
         __syncthreads();  // the other parity is free again: its readers passed this barrier's predecessor
@@ -518,14 +652,418 @@ __global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, co
         }
         if (bm != 0ull && best == bm) {  // keys are unique, so exactly one thread advances one list
 #pragma unroll
-            for (int j = 0; j < kMergeMaxOwned; ++j) {
+            for (int j = 0; j < OWN; ++j) {
                 if (head[j] == bm) {
                     const int l = tid + 256 * j;
-                    pos[j] += 1;
-                    head[j] = next[j];
-                    next[j] = pos[j] + 1 < k ? src.get(q, l, pos[j] + 1) : 0ull;
+                    const int np = ++pos[j];
+                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < k ? src.get(q, l, np) : 0ull);
                 }
             }
+        }
+    }
+}
+
+// ---- two-stage exact search: screening copy, certificate, exact second stage ---------------------
+//
+// Stage 1 (scan_topk_kernel<P = 1>) reads a scaled fp16 copy of the corpus — half the bytes of the
+// fp32 scan, and the matrix work drops to 1/16 — and keeps, per query and workgroup, every row whose
+// *approximate* score lies within 2 eps of the workgroup's running k-th best.  screen_collect_kernel
+// then gathers the rows within 2 eps of the global k-th best approximate score (at most k' of them),
+// and stage 2 recomputes their canonical fp32 scores and ranks them.  With |approx - exact| <= eps
+// for every row, the k rows with the best approximate scores have exact scores >= a_k - eps, so the
+// k-th exact score is >= a_k - eps, so every true top-k row has approx >= a_k - 2 eps: it is in the
+// band.  The result is therefore the exact top-k (bit-identical to the one-pass fp32 search) whenever
+// the whole band was kept — the certificate.  eps is a worst-case bound, not an estimate:
+//   fp16 rounding of both operands (values pre-scaled by powers of two so that neither overflow nor
+//   flushed subnormals matter)          (2^-10 + 2^-22) sum|q_i x_i|  <=  ... ||q|| ||x||
+//   anything below the fp16 normal range treated as lost   sqrt(d) (||q|| amax_x + ||x|| amax_q) 2^-27
+//   fp32 accumulation in the matrix core, in any order, and the canonical chain itself
+//                                        6 d 2^-24 ||q|| ||x||
+// Queries whose certificate fails (dense near-ties: a band wider than the buffers; non-finite or
+// out-of-range values) are re-run through the fp32 scan: the fallback launches are always enqueued
+// and switch themselves off on the device when no query needs them.
+
+struct ScreenCorpusStats {  // device words updated with atomics while rows are added
+    uint32_t absmax_bits;   // max |x_ij| as float bits
+    uint32_t sqnorm_bits;   // max ||x_i||^2 as float bits
+    uint32_t bad;           // a non-finite element was seen
+    uint32_t pad;
+};
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// One wave per row, grid-stride; the running maxima stay in registers until the end.
+__global__ __launch_bounds__(256) void screen_stats_kernel(const float* X, long long row_stride, int d8, long long row0,
+                                                           long long n, ScreenCorpusStats* st) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+    float amax = 0.f, nmax = 0.f;
+    bool bad = false;
+    for (long long i = wave; i < n; i += n_waves) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(X + (row0 + i) * row_stride);
+        float ss = 0.f;
+        for (int c = lane; c < d8 / 4; c += 64) {
+            const f32x4 v = src[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = fabsf(v[j]);
+                bad |= !(a <= 3.0e38f);
+                amax = fmaxf(amax, a);
+                ss = __builtin_fmaf(a, a, ss);
+            }
+        }
+        ss = wave_sum_f32(ss);
+        bad |= !(ss <= 3.0e38f);
+        nmax = fmaxf(nmax, ss);
+    }
+    amax = wave_max_f32(amax);
+    const bool any_bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        atomicMax(&st->absmax_bits, __float_as_uint(amax));  // non-negative floats order like their bits
+        atomicMax(&st->sqnorm_bits, __float_as_uint(nmax));
+        if (any_bad) atomicOr(&st->bad, 1u);
+    }
+}
+
+// X (fp32, stride d8) -> X16 (fp16, stride d64 halves, zero padded), values multiplied by `scale`.
+__global__ __launch_bounds__(256) void screen_convert_kernel(const float* X, long long row_stride, int d8, long long row0,
+                                                             long long n, float scale, _Float16* X16, int d64) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_waves = (long long)gridDim.x * 4;
+    for (long long i = wave; i < n; i += n_waves) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(X + (row0 + i) * row_stride);
+        f16x8* dst = reinterpret_cast<f16x8*>(X16 + (row0 + i) * (long long)d64);
+        for (int c = lane; c < d64 / 8; c += 64) {
+            f16x8 o;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (8 * c + 4 * hh < d8) v = src[2 * c + hh];  // d8 is a multiple of 4
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[4 * hh + j] = (_Float16)(v[j] * scale);
+            }
+            dst[c] = o;
+        }
+    }
+}
+
+struct ScreenQueryState {   // per pass of <= 32 queries (device memory)
+    float qscale[kQT];
+    float unscale[kQT];
+    float margin[kQT];      // 2 eps (4 eps for L2 ranking scores)
+    uint32_t lossy[kQT];    // certificate void: out-of-range query, or a workgroup dropped part of the band
+    uint32_t overflow[kQT]; // certificate void: the band did not fit the candidate list (screen_collect_kernel)
+    uint32_t fallback[kQT]; // set by the finalize kernel: this query goes through the fp32 scan
+    uint32_t any_fallback;  // the fallback launches read this word
+    uint32_t pad[3];
+};
+
+struct ScreenCounters {     // cumulative, read back by rag_index_screen_stats
+    unsigned long long queries;
+    unsigned long long fallbacks;
+    uint32_t max_err_ratio_bits;  // max observed |approx - exact| / eps over all verified candidates
+    uint32_t pad;
+};
+
+// One workgroup per query: norms -> scales and margins; clears the per-pass flags.  d <= 1024, so a
+// thread reads at most four elements and all of its loads are in flight together.
+__global__ __launch_bounds__(256) void screen_prep_kernel(const float* Q, int nq, int d, int d64, int l2, float x_absmax,
+                                                          float x_normmax, float x_scale, ScreenQueryState* qs) {
+    __shared__ float s_ss[4], s_am[4];
+    const int tid = threadIdx.x, q = blockIdx.x;  // grid = kQT: every slot of the state is rewritten
+    if (q == 0 && tid == 0) qs->any_fallback = 0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (q < nq) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = tid + 256 * u;
+            if (c < d) v[u] = Q[(size_t)q * d + c];
+        }
+    }
+    float ss = 0.f, amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float a = fabsf(v[u]);
+        amax = (a <= 3.0e38f) ? fmaxf(amax, a) : __builtin_inff();  // NaN / inf poison the maximum
+        ss = __builtin_fmaf(a, a, ss);
+    }
+    ss = wave_sum_f32(ss);
+    amax = wave_max_f32(amax);
+    if ((tid & 63) == 0) {
+        s_ss[tid >> 6] = ss;
+        s_am[tid >> 6] = amax;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    ss = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+    amax = fmaxf(fmaxf(s_am[0], s_am[1]), fmaxf(s_am[2], s_am[3]));
+    float qscale = 1.f, unscale = 0.f, margin = 0.f;
+    uint32_t lossy = 0;
+    if (q < nq) {
+        // usable range: the scales and their product must stay ordinary fp32 numbers
+        const bool ok = ss <= 1.0e24f && (amax == 0.f || (amax >= 1.0e-12f && amax <= 1.0e12f));
+        if (!ok) {
+            lossy = 1;
+        } else {
+            int e = 0;
+            if (amax > 0.f) (void)frexpf(amax, &e);     // amax = m 2^e, m in [0.5, 1)
+            qscale = ldexpf(1.f, 14 - e);                 // |q| qscale < 2^14
+            unscale = 1.f / (qscale * x_scale);           // powers of two: exact
+            const float qn = sqrtf(ss) * 1.0001f;
+            const float rel = 0.0009775f + 6.f * (float)d64 * 5.9604645e-8f;  // 2^-10 (1 + 2^-11) rounded up; 6 d 2^-24
+            const float eps = qn * x_normmax * rel +
+                              sqrtf((float)d64) * (qn * x_absmax + x_normmax * amax) * 7.4505806e-9f;  // 2^-27
+            margin = 2.f * eps * 1.01f * (l2 ? 2.f : 1.f);
+        }
+    }
+    qs->qscale[q] = qscale;
+    qs->unscale[q] = unscale;
+    qs->margin[q] = margin;
+    qs->lossy[q] = lossy;
+    qs->fallback[q] = 0;
+}
+
+// Candidate collection.  Per query: (A) the k-th best approximate key over all workgroup lists, by
+// the same tournament as the merge kernel, k rounds; (B) every listed row whose approximate score is
+// within the query's margin of it, appended in arbitrary order (stage 2 ranks by exact key).  The
+// certificate needs the *whole* band: more than kp - 1 band rows, or a workgroup list that lies
+// entirely inside the band (it may have been cut at kout), void it.
+struct ScreenCandidates {
+    float* approx;        // [kQT][kp] approximate ranking scores
+    long long* rows;      // [kQT][kp] local row numbers, -1 = empty
+    uint32_t* overflow;   // [kQT] certificate void: band wider than kp or cut short
+};
+
+template <int OWN>
+__global__ __launch_bounds__(256) void screen_collect_kernel(const KeyListSrc src, const int n_lists, const int k,
+                                                             const int kp, const int look, const float* margin,
+                                                             const ScreenCandidates out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* ahead = reinterpret_cast<u64*>(smem);  // [n_lists][look], as in tournament_merge_kernel
+    __shared__ u64 wmax[2][4];
+    __shared__ uint32_t s_cnt, s_cut;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int kout = src.k;
+    for (int idx = tid; idx < n_lists * look; idx += 256) {
+        const int l = idx / look, p = idx - l * look;
+        ahead[idx] = src.get(q, l, p);
+    }
+    if (tid == 0) {
+        s_cnt = 0;
+        s_cut = 0;
+    }
+    __syncthreads();
+    u64 head[OWN];
+    int pos[OWN];
+#pragma unroll
+    for (int j = 0; j < OWN; ++j) {
+        const int l = tid + 256 * j;
+        pos[j] = 0;
+        head[j] = l < n_lists ? ahead[(size_t)l * look] : 0ull;
+    }
+    u64 kth = 0ull;
+    for (int round = 0; round < k; ++round) {
+        u64 best = head[0];
+#pragma unroll
+        for (int j = 1; j < OWN; ++j) best = umax64(best, head[j]);
+        const u64 wm = wave_max_u64(best);
+        if ((tid & 63) == 0) wmax[round & 1][tid >> 6] = wm;
+        __syncthreads();
+        const u64 bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]),
+                              umax64(wmax[round & 1][2], wmax[round & 1][3]));
+        kth = bm;
+        if (bm == 0ull) break;  // fewer than k rows in all: everything listed is a candidate
+        if (best == bm) {
+#pragma unroll
+            for (int j = 0; j < OWN; ++j) {
+                if (head[j] == bm) {
+                    const int l = tid + 256 * j;
+                    const int np = ++pos[j];
+                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < kout ? src.get(q, l, np) : 0ull);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const float thr = kth != 0ull ? unord32((uint32_t)(kth >> 32)) - margin[q] : -__builtin_inff();
+    for (int l = tid; l < n_lists; l += 256) {
+        int p = 0;
+        for (; p < kout; ++p) {
+            const u64 key = p < look ? ahead[(size_t)l * look + p] : src.get(q, l, p);
+            if (key == 0ull) break;
+            const float a = unord32((uint32_t)(key >> 32));
+            if (a < thr) break;
+            const uint32_t slot = atomicAdd(&s_cnt, 1u);
+            if (slot < (uint32_t)kp) {
+                out.approx[(size_t)q * kp + slot] = a;
+                out.rows[(size_t)q * kp + slot] = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+            }
+        }
+        if (p == kout) s_cut = 1;  // the whole list is in the band: rows below its cut may be too
+    }
+    __syncthreads();
+    const uint32_t n = s_cnt;
+    for (int i = (int)min(n, (uint32_t)kp) + tid; i < kp; i += 256) out.rows[(size_t)q * kp + i] = -1;
+    if (tid == 0) out.overflow[q] = (n >= (uint32_t)kp || s_cut) ? 1u : 0u;
+}
+
+// Exact second stage: canonical fp32 score of candidate (q, j), as a ranking key (0 for an empty slot).
+// One 64-thread workgroup stages 8 candidate rows in LDS with coalesced loads (all of a thread's loads
+// in flight together); 8 lanes then run the 8 fmaf chains (oracle/flat_oracle.c:rago_dot order) out
+// of LDS with 16-byte reads.
+constexpr int kVerifyRows = 8;
+__host__ __device__ inline size_t verify_lds_bytes(int d8) {
+    return ((size_t)kVerifyRows * (d8 + 4) + d8) * sizeof(float);
+}
+
+__global__ __launch_bounds__(64) void screen_verify_kernel(const float* X, long long row_stride, const float* xnorm,
+                                                           const float* Q, int d, int d8, int l2, int kp,
+                                                           const long long* cand_rows, u64* exact_keys) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* rows = reinterpret_cast<float*>(smem);
+    float* qv = rows + (size_t)kVerifyRows * (d8 + 4);
+    const int q = blockIdx.y, c0 = blockIdx.x * kVerifyRows, tid = threadIdx.x;
+    long long my_id = -1;
+    if (tid < kVerifyRows && c0 + tid < kp) my_id = cand_rows[(size_t)q * kp + c0 + tid];
+    if (__ballot(my_id >= 0) == 0ull) {  // nothing to score in this group
+        if (tid < kVerifyRows && c0 + tid < kp) exact_keys[(size_t)q * kp + c0 + tid] = 0ull;
+        return;
+    }
+    const int d4 = d8 / 4;  // <= 256 (d <= 1024)
+    {   // all of a thread's row loads are issued before the first LDS store (one memory latency, not eight)
+        f32x4 v[kVerifyRows][4];
+        float qreg[16];
+#pragma unroll
+        for (int j = 0; j < kVerifyRows; ++j) {
+            const long long id = __shfl(my_id, j, 64);
+            const f32x4* src = reinterpret_cast<const f32x4*>(X + (id < 0 ? 0 : id) * row_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = tid + 64 * u;
+                v[j][u] = (id >= 0 && c < d4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = tid + 64 * u;
+            qreg[u] = c < d ? Q[(size_t)q * d + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < kVerifyRows; ++j) {
+            f32x4* dst = reinterpret_cast<f32x4*>(rows + (size_t)j * (d8 + 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = tid + 64 * u;
+                if (c < d4) dst[c] = v[j][u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = tid + 64 * u;
+            if (c < d8) qv[c] = qreg[u];
+        }
+    }
+    __syncthreads();
+    if (tid >= kVerifyRows || c0 + tid >= kp) return;
+    u64 key = 0ull;
+    if (my_id >= 0) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(rows + (size_t)tid * (d8 + 4));
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(qv);
+        float acc = 0.f;
+        f32x4 xa = x4[0], xb = x4[1], qa = q4[0], qb = q4[1];
+        for (int s = 2; s <= d4; s += 2) {  // operands of the next group are read under this group's chain
+            const int sn = s < d4 ? s : 0;
+            const f32x4 xa_n = x4[sn], xb_n = x4[sn + 1], qa_n = q4[sn], qb_n = q4[sn + 1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = __builtin_fmaf(xa[t], qa[t], acc);
+                acc = __builtin_fmaf(xb[t], qb[t], acc);
+            }
+            xa = xa_n;
+            xb = xb_n;
+            qa = qa_n;
+            qb = qb_n;
+        }
+        float score = acc + 0.0f;
+        if (l2) score = __builtin_fmaf(2.0f, acc, -xnorm[my_id]) + 0.0f;
+        key = make_key(score, (uint32_t)my_id);
+    }
+    exact_keys[(size_t)q * kp + c0 + tid] = key;
+}
+
+// One wave per query: certificate, rank the exact keys, write the results.  kp <= 64 * E.
+template <int E>
+__global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx, const long long* cand_rows,
+                                                             const u64* exact_keys, const uint32_t* overflow, int kp,
+                                                             int k, int l2, const float* qnorm, long long id_offset,
+                                                             ScreenQueryState* qs, ScreenCounters* ctr, float* out_s,
+                                                             long long* out_i) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    u64 kk[1][E];
+    float worst = 0.f;
+    const float margin = qs->margin[q];
+    const float eps = margin * (l2 ? 0.25f : 0.5f);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = e * 64 + lane;
+        u64 key = 0ull;
+        if (idx < kp && cand_rows[(size_t)q * kp + idx] >= 0) {
+            key = exact_keys[(size_t)q * kp + idx];
+            const float ex = unord32((uint32_t)(key >> 32));
+            const float err = fabsf(approx[(size_t)q * kp + idx] - ex) * (l2 ? 0.5f : 1.f);
+            worst = fmaxf(worst, err);
+        }
+        kk[0][e] = key;
+    }
+    worst = wave_max_f32(worst);
+    // certificate: the scan kept the whole band (not lossy), the collection held it (no overflow), and —
+    // belt and braces — no verified candidate shows an error beyond the bound the band was built from
+    bool ok = qs->lossy[q] == 0 && overflow[q] == 0;
+    if (ok && !(worst <= eps)) ok = false;  // also catches eps == 0 with any error, and NaN
+    wave_sort_desc<E, 1>(kk, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int idx = e * 64 + lane;
+        if (idx < k) {
+            const u64 key = kk[0][e];
+            float s;
+            long long id;
+            if (key == 0ull) {
+                s = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+                id = -1;
+            } else {
+                const float rs = unord32((uint32_t)(key >> 32));
+                if (l2) {
+                    const float dist = qnorm[q] - rs;
+                    s = dist < 0.f ? 0.f : dist;
+                } else {
+                    s = rs;
+                }
+                id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + id_offset;
+            }
+            out_s[(size_t)q * k + idx] = s;
+            out_i[(size_t)q * k + idx] = id;
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&ctr->queries, 1ull);
+        if (!ok) {
+            qs->fallback[q] = 1;
+            atomicOr(&qs->any_fallback, 1u);
+            atomicAdd(&ctr->fallbacks, 1ull);
+        } else if (eps > 0.f) {
+            atomicMax(&ctr->max_err_ratio_bits, __float_as_uint(worst / eps));
         }
     }
 }

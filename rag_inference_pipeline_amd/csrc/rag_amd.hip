@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -71,7 +72,22 @@ using ScanFn = void (*)(const ragk::ScanParams);
 
 template <int NW, int E, int D>
 ScanFn scan_fn_metric(bool l2) {
-    return l2 ? (ScanFn)ragk::scan_topk_kernel<NW, E, D, true> : (ScanFn)ragk::scan_topk_kernel<NW, E, D, false>;
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<NW, E, D, true, 0> : (ScanFn)ragk::scan_topk_kernel<NW, E, D, false, 0>;
+}
+
+// screening pass (fp16 copy): 8 waves, ring 8 or 4
+template <int E>
+ScanFn screen_fn_cap(int ring, bool l2) {
+    if (ring == 8)
+        return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 8, true, 1> : (ScanFn)ragk::scan_topk_kernel<8, E, 8, false, 1>;
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 4, true, 1> : (ScanFn)ragk::scan_topk_kernel<8, E, 4, false, 1>;
+}
+ScanFn screen_fn(int cap, int ring, bool l2) {
+    switch (cap) {
+        case 64: return screen_fn_cap<1>(ring, l2);
+        case 128: return screen_fn_cap<2>(ring, l2);
+        default: return screen_fn_cap<4>(ring, l2);
+    }
 }
 template <int NW, int E>
 ScanFn scan_fn_ring(int ring, bool l2) {
@@ -147,6 +163,17 @@ struct rag_index {
     hipStream_t ws_stream = nullptr;
     bool ws_used = false;
 
+    // two-stage search (rag_index_set_screening): scaled fp16 copy of the corpus + certificate state
+    bool screen_on = false;      // requested
+    bool screen_valid = false;   // the copy exists and the corpus is inside the range the bound covers
+    _Float16* X16 = nullptr;     // cap_rows x d64
+    int d64 = 0;
+    float x_absmax = 0.f, x_normmax = 0.f, x_scale = 0.f;  // x_scale == 0: not chosen yet
+    ragk::ScreenCorpusStats* sc_stats = nullptr;
+    ragk::ScreenQueryState* sq = nullptr;
+    ragk::ScreenCounters* sctr = nullptr;
+    float* cand_s = nullptr; long long* cand_i = nullptr; ragk::u64* cand_keys = nullptr; size_t cand_cap = 0;
+
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -176,6 +203,21 @@ int grow_rows(rag_index* h, long long want) {
         if (nn) HIP_TRY(hipMemcpyAsync(nn, h->xnorm, (size_t)h->n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    if (h->screen_on) {
+        _Float16* n16 = nullptr;
+        rc = dev_alloc(&n16, (size_t)cap * h->d64);
+        if (rc) {
+            (void)hipFree(nx);
+            if (nn) (void)hipFree(nn);
+            return rc;
+        }
+        if (h->n > 0 && h->X16) {
+            HIP_TRY(hipMemcpyAsync(n16, h->X16, (size_t)h->n * h->d64 * sizeof(_Float16), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+        if (h->X16) (void)hipFree(h->X16);
+        h->X16 = n16;
+    }
     if (h->X) (void)hipFree(h->X);
     if (h->xnorm) (void)hipFree(h->xnorm);
     h->X = nx;
@@ -188,6 +230,42 @@ int grow_rows(rag_index* h, long long want) {
     return RAG_OK;
 }
 
+// Bring the fp16 screening copy up to date for rows [row0, row0 + n) that have just landed in X.
+// Synchronises `st` (the maxima decide the scale, and with it whether everything is converted again).
+int screen_sync_rows(rag_index* h, long long row0, long long n, hipStream_t st) {
+    using namespace ragk;
+    if (!h->screen_on || n <= 0) return RAG_OK;
+    const unsigned grid = (unsigned)std::min<long long>((n + 3) / 4, 4096);
+    screen_stats_kernel<<<dim3(grid), dim3(256), 0, st>>>(h->X, h->d8, h->d8, row0, n, h->sc_stats);
+    HIP_TRY(hipGetLastError());
+    ScreenCorpusStats cs;
+    HIP_TRY(hipMemcpyAsync(&cs, h->sc_stats, sizeof cs, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float absmax, sqn;
+    std::memcpy(&absmax, &cs.absmax_bits, 4);
+    std::memcpy(&sqn, &cs.sqnorm_bits, 4);
+    const bool was_valid = h->screen_valid;
+    h->screen_valid = false;
+    if (cs.bad || !(sqn <= 1.0e24f) || (absmax != 0.f && !(absmax >= 1.0e-12f && absmax <= 1.0e12f)))
+        return RAG_OK;  // outside the range the error bound covers: searches use the fp32 scan
+    h->x_absmax = absmax;
+    h->x_normmax = std::sqrt(sqn) * 1.0001f;
+    long long c0 = row0, cn = n;
+    if (!was_valid || h->x_scale == 0.f || !(absmax * h->x_scale < 32768.f)) {  // (re)choose the scale: convert every row
+        int e = 0;
+        if (absmax > 0.f) (void)std::frexp(absmax, &e);
+        h->x_scale = std::ldexp(1.f, 14 - e);
+        c0 = 0;
+        cn = row0 + n;
+    }
+    const unsigned cgrid = (unsigned)std::min<long long>((cn + 3) / 4, 4096);
+    screen_convert_kernel<<<dim3(cgrid), dim3(256), 0, st>>>(h->X, h->d8, h->d8, c0, cn, h->x_scale, h->X16, h->d64);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    h->screen_valid = true;
+    return RAG_OK;
+}
+
 int after_add(rag_index* h, long long row0, long long n, hipStream_t st) {
     if (h->metric == RAG_METRIC_L2 && n > 0) {
         const int bs = 256;
@@ -195,7 +273,35 @@ int after_add(rag_index* h, long long row0, long long n, hipStream_t st) {
                                                                                          h->xnorm);
         HIP_TRY(hipGetLastError());
     }
-    return RAG_OK;
+    return screen_sync_rows(h, row0, n, st);
+}
+
+template <class Src>
+void launch_merge(const Src& src, int n_lists, int nq, int k, int look, const ragk::MergeOut& mo, hipStream_t st) {
+    using namespace ragk;
+    const size_t lds = (size_t)n_lists * look * 8;
+    if (n_lists <= 256)
+        tournament_merge_kernel<Src, 1><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+    else if (n_lists <= 512)
+        tournament_merge_kernel<Src, 2><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+    else
+        tournament_merge_kernel<Src, kMergeMaxOwned><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+}
+
+void prof_push(rag_index* h, hipEvent_t e0, hipEvent_t e1) {
+    h->prof_events.emplace_back(e0, e1);
+    if (h->prof_events.size() >= 4096) {  // nobody is collecting: fold what has finished into the totals
+        for (auto& ev : h->prof_events) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                h->prof_ms += ms;
+                h->prof_launches += 1;
+            }
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        h->prof_events.clear();
+    }
 }
 
 int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
@@ -219,8 +325,11 @@ int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
 // One pass of <= 32 queries: scan + merge into out (device pointers, row stride k).
 // `ceil` (device, kQT keys, or null) restricts candidates to keys below it; `last_key` (device, kQT keys, or
 // null) receives each query's k-th key; results go to columns [0, k) of rows of `out_stride` elements.
+// `enable` / `qmask` (device words, or null) make this the fallback of the two-stage search: with
+// *enable == 0 every launch returns at once, otherwise only queries with qmask[q] != 0 are written.
 int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u64* ceil, ragk::u64* last_key,
-                 float* out_s, long long* out_i, int out_stride, hipStream_t st) {
+                 float* out_s, long long* out_i, int out_stride, hipStream_t st, const uint32_t* enable = nullptr,
+                 const uint32_t* qmask = nullptr) {
     using namespace ragk;
     const int dc_full = chunk_cols(h->d8);
     const int cap = pick_capacity(dc_full, k);
@@ -250,7 +359,8 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
     }
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->prof) {
+    const bool timed = h->prof && !enable;
+    if (timed) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
@@ -286,36 +396,162 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.k = k;
         sp.n_tiles = n_tiles;
         sp.n_iters = n_iters;
+        sp.enable = enable;
+        sp.kout = k;
+        sp.qscale = sp.unscale = sp.margin = nullptr;
+        sp.lossy = nullptr;
         ScanFn fn = scan_fn(waves, cap, ring, l2);
         const size_t lds = scan_lds_bytes(dc8, cap);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
         HIP_TRY(hipGetLastError());
     }
-    if (h->prof) {
+    if (timed) {
         HIP_TRY(hipEventRecord(e1, st));
-        h->prof_events.emplace_back(e0, e1);
-        if (h->prof_events.size() >= 4096) {  // nobody is collecting: fold what has finished into the totals
-            for (auto& ev : h->prof_events) {
-                float ms = 0.f;
-                if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
-                    h->prof_ms += ms;
-                    h->prof_launches += 1;
-                }
-                (void)hipEventDestroy(ev.first);
-                (void)hipEventDestroy(ev.second);
-            }
-            h->prof_events.clear();
-        }
+        prof_push(h, e0, e1);
     }
 
     // merge: per query the top-k of the grid sorted lists, decoded into (score, id)
     if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
     KeyListSrc src{h->partial, grid, k};
-    MergeOut mo{out_s, out_i, last_key, out_stride, h->qnorm, h->id_offset, h->metric, 0};
-    tournament_merge_kernel<KeyListSrc><<<dim3(nq), dim3(256), 0, st>>>(src, grid, k, mo);
+    MergeOut mo{out_s, out_i, last_key, out_stride, h->qnorm, h->id_offset, h->metric, 0, qmask};
+    const int look = merge_look(grid, k, k);
+    launch_merge(src, grid, nq, k, look, mo, st);
     HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+
+// Exact search of one block of <= 32 queries, any k: rounds of kmax when k exceeds what one fused pass
+// can select (LDS budget), each round a full scan restricted to keys below the previous round's last key.
+int search_exact_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st,
+                       const uint32_t* enable = nullptr, const uint32_t* qmask = nullptr) {
+    const int kmax = rag_index_max_k(h->d, nb);
+    if (kmax <= 0) return fail(RAG_ERR_UNSUPPORTED, "dimension %d is not supported by the scan kernel", h->d);
+    if (k <= kmax) return search_round(h, qp, nb, k, nullptr, nullptr, os, oi, k, st, enable, qmask);
+    if (!h->round_keys) {
+        int rc = dev_alloc(&h->round_keys, (size_t)2 * ragk::kQT);
+        if (rc) return rc;
+    }
+    int done = 0, flip = 0;
+    while (done < k) {
+        const int kr = std::min(kmax, k - done);
+        const ragk::u64* ceil = done ? h->round_keys + (size_t)flip * ragk::kQT : nullptr;
+        ragk::u64* last = h->round_keys + (size_t)(flip ^ 1) * ragk::kQT;
+        int rc = search_round(h, qp, nb, kr, ceil, last, os + done, oi + done, k, st, enable, qmask);
+        if (rc) return rc;
+        done += kr;
+        flip ^= 1;
+    }
+    return RAG_OK;
+}
+
+// Two-stage search of one block of <= 32 queries (see flat_kernels.hip.h, "two-stage exact search"):
+// fp16 screening scan -> k' candidates -> canonical fp32 scores -> certificate; queries that fail it
+// are answered by the fallback launches of the fp32 scan (no-ops otherwise).
+constexpr int kScreenMaxK = 100;
+constexpr int kScreenMaxD64 = 1024;
+
+int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st) {
+    using namespace ragk;
+    const int kp = k <= 16 ? 64 : (k <= 48 ? 128 : 240);
+    const int cap = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
+    const bool l2 = h->metric == RAG_METRIC_L2;
+    const int waves = 8;
+    const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
+    const int n_tiles = (int)n_tiles_ll;
+    int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + waves - 1) / waves);
+    grid = std::max(grid, 1);
+    const int n_iters = (n_tiles + grid * waves - 1) / (grid * waves);
+    if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
+
+    int rc = ensure_search_ws(h, nb, kp, grid);
+    if (rc) return rc;
+    const size_t cand = (size_t)kQT * kp;
+    if (cand > h->cand_cap) {
+        void* old[] = {h->cand_s, h->cand_i, h->cand_keys};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
+        h->cand_s = nullptr;
+        h->cand_i = nullptr;
+        h->cand_keys = nullptr;
+        h->cand_cap = 0;
+        if ((rc = dev_alloc(&h->cand_s, cand)) || (rc = dev_alloc(&h->cand_i, cand)) || (rc = dev_alloc(&h->cand_keys, cand)))
+            return rc;
+        h->cand_cap = cand;
+    }
+    if (l2) {
+        row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(qp, h->d, h->d, 0, nb, h->qnorm);
+        HIP_TRY(hipGetLastError());
+    }
+    screen_prep_kernel<<<dim3(kQT), dim3(256), 0, st>>>(qp, nb, h->d, h->d64, l2 ? 1 : 0, h->x_absmax, h->x_normmax,
+                                                           h->x_scale, h->sq);
+    HIP_TRY(hipGetLastError());
+
+    // stage 1: screening scan over the fp16 copy (addresses in 4-byte units: 16 halves = 8 units per step)
+    ScanParams sp;
+    sp.X = reinterpret_cast<const float*>(h->X16);
+    sp.xnorm = h->xnorm;
+    sp.Q = qp;
+    sp.partial = h->partial;
+    sp.ceil = nullptr;
+    sp.acc_io = nullptr;
+    sp.col0 = 0;
+    sp.dc8 = h->d64 / 2;
+    sp.acc_in = 0;
+    sp.acc_out = 0;
+    sp.n_rows = h->n;
+    sp.row_stride = h->d64 / 2;
+    sp.d = h->d;
+    sp.d8 = h->d8;
+    sp.nq = nb;
+    sp.k = k;
+    sp.n_tiles = n_tiles;
+    sp.n_iters = n_iters;
+    sp.enable = nullptr;
+    sp.kout = kp;
+    sp.qscale = h->sq->qscale;
+    sp.unscale = h->sq->unscale;
+    sp.margin = h->sq->margin;
+    sp.lossy = h->sq->lossy;
+    const int S = h->d64 / 16;
+    ScanFn fn = screen_fn(cap, S % 8 == 0 ? 8 : 4, l2);
+    const size_t lds = scan_lds_bytes(h->d64 / 2, cap);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
+    HIP_TRY(hipGetLastError());
+    if (h->prof) {
+        HIP_TRY(hipEventRecord(e1, st));
+        prof_push(h, e0, e1);
+    }
+
+    // the band below the k-th best approximate key of every query -> (approximate ranking score, local row)
+    KeyListSrc src{h->partial, grid, kp};
+    ScreenCandidates cands{h->cand_s, h->cand_i, h->sq->overflow};
+    const int look = merge_look(grid, kp, k);
+    auto collect = grid <= 256 ? screen_collect_kernel<1> : (grid <= 512 ? screen_collect_kernel<2> : screen_collect_kernel<kMergeMaxOwned>);
+    collect<<<dim3(nb), dim3(256), (size_t)grid * look * 8, st>>>(src, grid, k, kp, look, h->sq->margin, cands);
+    HIP_TRY(hipGetLastError());
+
+    // stage 2: canonical fp32 scores of the candidates, certificate, results
+    const size_t vlds = verify_lds_bytes(h->d8);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_verify_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
+    screen_verify_kernel<<<dim3((kp + kVerifyRows - 1) / kVerifyRows, nb), dim3(64), vlds, st>>>(
+        h->X, h->d8, h->xnorm, qp, h->d, h->d8, l2 ? 1 : 0, kp, h->cand_i, h->cand_keys);
+    HIP_TRY(hipGetLastError());
+    auto fin = kp <= 64 ? screen_finalize_kernel<1> : (kp <= 128 ? screen_finalize_kernel<2> : screen_finalize_kernel<4>);
+    fin<<<dim3(nb), dim3(64), 0, st>>>(h->cand_s, h->cand_i, h->cand_keys, h->sq->overflow, kp, k, l2 ? 1 : 0, h->qnorm,
+                                       h->id_offset, h->sq, h->sctr, os, oi);
+    HIP_TRY(hipGetLastError());
+
+    // fallback: the fp32 search of this block, enqueued unconditionally, a no-op unless a certificate failed
+    return search_exact_block(h, qp, nb, k, os, oi, st, &h->sq->any_fallback, h->sq->fallback);
 }
 
 int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i,
@@ -337,34 +573,14 @@ int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float*
         HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    // k beyond what one fused pass can select (LDS budget): take the results in rounds of kmax, each
-    // round a full scan restricted to keys below the previous round's last key.
-    const int kmax = rag_index_max_k(h->d, nq);
-    if (kmax <= 0) return fail(RAG_ERR_UNSUPPORTED, "dimension %d is not supported by the scan kernel", h->d);
-    if (k > kmax && !h->round_keys) {
-        int rc = dev_alloc(&h->round_keys, (size_t)2 * ragk::kQT);
-        if (rc) return rc;
-    }
+    const bool screened = h->screen_on && h->screen_valid && k <= kScreenMaxK && h->d64 <= kScreenMaxD64;
     for (int q0 = 0; q0 < nq; q0 += ragk::kQT) {
         const int nb = std::min(ragk::kQT, nq - q0);
         const float* qp = q_dev + (size_t)q0 * h->d;
         float* os = out_s + (size_t)q0 * k;
         long long* oi = out_i + (size_t)q0 * k;
-        if (k <= kmax) {
-            int rc = search_round(h, qp, nb, k, nullptr, nullptr, os, oi, k, st);
-            if (rc) return rc;
-            continue;
-        }
-        int done = 0, flip = 0;
-        while (done < k) {
-            const int kr = std::min(kmax, k - done);
-            const ragk::u64* ceil = done ? h->round_keys + (size_t)flip * ragk::kQT : nullptr;
-            ragk::u64* last = h->round_keys + (size_t)(flip ^ 1) * ragk::kQT;
-            int rc = search_round(h, qp, nb, kr, ceil, last, os + done, oi + done, k, st);
-            if (rc) return rc;
-            done += kr;
-            flip ^= 1;
-        }
+        int rc = screened ? search_screened_block(h, qp, nb, k, os, oi, st) : search_exact_block(h, qp, nb, k, os, oi, st);
+        if (rc) return rc;
     }
     return RAG_OK;
 }
@@ -436,7 +652,8 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
-        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev};
+        void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev,
+                         h->X16, h->sc_stats, h->sq, h->sctr, h->cand_s, h->cand_i, h->cand_keys};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
@@ -537,6 +754,68 @@ extern "C" int rag_index_set_id_offset(rag_index* h, int64_t id_offset) {
     if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
     std::lock_guard<std::mutex> lk(h->mu);
     h->id_offset = id_offset;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_set_screening(rag_index* h, int32_t mode) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    if (mode != RAG_SCREEN_OFF && mode != RAG_SCREEN_FP16) return fail(RAG_ERR_INVALID_ARG, "unknown screening mode %d", mode);
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_TRY(hipDeviceSynchronize());  // searches in flight may still read the copy
+    if (mode == RAG_SCREEN_OFF) {
+        if (h->X16) (void)hipFree(h->X16);
+        h->X16 = nullptr;
+        h->screen_on = h->screen_valid = false;
+        h->x_scale = 0.f;
+        return RAG_OK;
+    }
+    if (h->screen_on) return RAG_OK;
+    const int d64 = round_up(h->d, 64);
+    if (d64 > kScreenMaxD64)
+        return fail(RAG_ERR_UNSUPPORTED, "two-stage search covers d <= %d (d = %d)", kScreenMaxD64, h->d);
+    int rc;
+    if (!h->sc_stats && (rc = dev_alloc(&h->sc_stats, 1))) return rc;
+    if (!h->sq && (rc = dev_alloc(&h->sq, 1))) return rc;
+    if (!h->sctr && (rc = dev_alloc(&h->sctr, 1))) return rc;
+    HIP_TRY(hipMemset(h->sc_stats, 0, sizeof(ragk::ScreenCorpusStats)));
+    HIP_TRY(hipMemset(h->sq, 0, sizeof(ragk::ScreenQueryState)));
+    HIP_TRY(hipMemset(h->sctr, 0, sizeof(ragk::ScreenCounters)));
+    if (h->cap_rows > 0 && (rc = dev_alloc(&h->X16, (size_t)h->cap_rows * d64))) return rc;
+    h->d64 = d64;
+    h->screen_on = true;
+    h->screen_valid = false;
+    h->x_scale = 0.f;
+    rc = screen_sync_rows(h, 0, h->n, h->stream);
+    if (rc) {
+        if (h->X16) (void)hipFree(h->X16);
+        h->X16 = nullptr;
+        h->screen_on = false;
+    }
+    return rc;
+}
+
+extern "C" int32_t rag_index_screening(const rag_index* h) {
+    if (!h || !h->screen_on) return RAG_SCREEN_OFF;
+    return h->screen_valid ? RAG_SCREEN_FP16 : RAG_SCREEN_INACTIVE;
+}
+
+extern "C" int rag_index_screen_stats(rag_index* h, int64_t* queries, int64_t* fallbacks, double* max_err_ratio,
+                                      int32_t reset) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    ragk::ScreenCounters c{};
+    if (h->sctr) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(&c, h->sctr, sizeof c, hipMemcpyDeviceToHost));
+        if (reset) HIP_TRY(hipMemset(h->sctr, 0, sizeof c));
+    }
+    float ratio;
+    std::memcpy(&ratio, &c.max_err_ratio_bits, 4);
+    if (queries) *queries = (int64_t)c.queries;
+    if (fallbacks) *fallbacks = (int64_t)c.fallbacks;
+    if (max_err_ratio) *max_err_ratio = ratio;
     return RAG_OK;
 }
 
@@ -679,8 +958,9 @@ int merge_shards(int device, int metric, int n_shards, int nq, int k, const floa
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
     ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
-    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1};
-    tournament_merge_kernel<ShardListSrc><<<dim3(nq), dim3(256), 0, (hipStream_t)stream>>>(src, n_shards, k, mo);
+    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr};
+    const int look = merge_look(n_shards, k, k);
+    launch_merge(src, n_shards, nq, k, look, mo, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return RAG_OK;
 }

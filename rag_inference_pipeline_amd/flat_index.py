@@ -14,6 +14,8 @@ import numpy as np
 from . import _native
 from ._native import METRIC_INNER_PRODUCT, METRIC_L2  # noqa: F401  (re-exported)
 
+SCREEN_OFF, SCREEN_FP16, SCREEN_INACTIVE = 0, 1, 2  # include/rag_amd.h RAG_SCREEN_*
+
 
 def _f32p(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
@@ -97,6 +99,24 @@ class FlatIndex:
         _native.check(self._lib.rag_index_search_device(
             self._handle(), C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(out_scores_ptr),
             C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
+
+    # -- two-stage exact search ------------------------------------------------------------
+    def set_screening(self, mode: int | bool = SCREEN_FP16) -> None:
+        """Keep a scaled fp16 copy of the corpus and answer k <= 100 searches by screening it, then
+        re-scoring the candidates in fp32 under a per-query exactness certificate (failures fall back
+        to the fp32 scan on the device).  Results are identical in either mode."""
+        _native.check(self._lib.rag_index_set_screening(self._handle(), int(mode)))
+
+    @property
+    def screening(self) -> int:
+        """SCREEN_OFF, SCREEN_FP16 (active) or SCREEN_INACTIVE (requested, corpus out of range)."""
+        return int(self._lib.rag_index_screening(self._handle()))
+
+    def screen_stats(self, reset: bool = False) -> dict:
+        q, f, r = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        _native.check(self._lib.rag_index_screen_stats(self._handle(), C.byref(q), C.byref(f), C.byref(r),
+                                                       1 if reset else 0))
+        return {"queries": int(q.value), "fallbacks": int(f.value), "max_err_ratio": float(r.value)}
 
     # -- profiling ------------------------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:

@@ -1,0 +1,229 @@
+"""GPU parity of the two-stage search (fp16 screening scan + exact fp32 second stage + certificate,
+include/rag_amd.h rag_index_set_screening): results must be what the one-pass fp32 search and the CPU
+oracle return, bit for bit, whether the certificate holds or the fallback runs."""
+import numpy as np
+import pytest
+
+from oracle import flat as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def _screened(X, metric=0):
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, FlatIndex
+    idx = FlatIndex(X.shape[1], metric)
+    idx.add(X)
+    idx.set_screening(SCREEN_FP16)
+    return idx
+
+
+def _check(idx, X, Q, k, metric=0):
+    D, I = idx.search(Q, k)
+    Do, Io = oracle.search(X, Q, k, metric)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+
+
+CASES = [
+    # (N, d, nq, k, metric)
+    (200_000, 384, 32, 10, 0),
+    (100_000, 768, 32, 10, 0),
+    (100_000, 768, 32, 1, 0),
+    (60_000, 768, 7, 16, 0),
+    (60_000, 768, 32, 17, 0),     # k' = 128
+    (60_000, 384, 45, 48, 0),     # two passes of queries
+    (60_000, 384, 32, 49, 0),     # k' = 240
+    (80_000, 768, 32, 100, 0),    # the rerank profile's k
+    (50_000, 768, 32, 10, 1),     # L2
+    (50_000, 384, 5, 100, 1),
+    (30_000, 100, 32, 10, 0),     # d padded to 128 in the fp16 copy
+    (30_000, 200, 3, 20, 1),      # padded to 256, ring of 4
+    (20_000, 1024, 32, 10, 0),    # largest d the screen covers
+    (20_000, 1000, 32, 60, 0),    # fallback needs rounds (k > max_k(1000) = 48) if it ever runs
+    (33, 64, 32, 10, 0),          # fewer rows than candidates
+    (5, 64, 2, 10, 0),            # k > N: -1 padding
+]
+
+
+@pytest.mark.parametrize("N,d,nq,k,metric", CASES)
+def test_screened_search_matches_oracle_bit_exact(gpu_required, N, d, nq, k, metric):
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16
+    rng = np.random.default_rng(99 + N + d + k)
+    X, Q = _unit(rng, N, d), _unit(rng, nq, d)
+    idx = _screened(X, metric)
+    assert idx.screening == SCREEN_FP16
+    _check(idx, X, Q, k, metric)
+    st = idx.screen_stats()
+    assert st["queries"] == nq
+    assert st["max_err_ratio"] < 1.0          # observed error inside the worst-case bound
+    idx.close()
+
+
+def test_error_bound_has_headroom_and_random_data_rarely_falls_back(gpu_required):
+    rng = np.random.default_rng(7)
+    X = _unit(rng, 300_000, 768)
+    idx = _screened(X)
+    for seed in range(4):
+        Q = _unit(np.random.default_rng(seed), 32, 768)
+        _check(idx, X, Q, 10)
+    st = idx.screen_stats()
+    assert st["queries"] == 128
+    assert st["fallbacks"] <= 2, st
+    assert 0.0 < st["max_err_ratio"] < 0.25, st   # fp16 rounding errors do not line up in practice
+    idx.close()
+
+
+def test_dense_near_ties_fall_back_and_stay_exact(gpu_required):
+    # 400 rows within ~1e-6 of each other at the top of every query's ranking: the band cannot be
+    # closed, the certificate fails, the fp32 fallback answers.
+    rng = np.random.default_rng(11)
+    d = 384
+    X = _unit(rng, 40_000, d)
+    centre = _unit(rng, 1, d)[0]
+    clones = centre[None, :] + 1e-6 * rng.standard_normal((400, d)).astype(np.float32)
+    clones /= np.linalg.norm(clones, axis=1, keepdims=True)
+    where = rng.choice(len(X), size=400, replace=False)
+    X[where] = clones.astype(np.float32)
+    Q = np.vstack([centre[None, :], _unit(rng, 31, d)]).astype(np.float32)
+    idx = _screened(X)
+    _check(idx, X, Q, 10)
+    st = idx.screen_stats()
+    assert st["fallbacks"] >= 1               # query 0 at least
+    _check(idx, X, Q, 100)
+    idx.close()
+
+
+def test_exact_duplicates_rank_by_ascending_id(gpu_required):
+    rng = np.random.default_rng(12)
+    X = _unit(rng, 20_000, 128)
+    X[[5, 77, 4000, 19_999]] = X[123]
+    Q = X[[123]].copy()
+    idx = _screened(X)
+    D, I = idx.search(Q, 8)
+    assert I[0, :5].tolist() == [5, 77, 123, 4000, 19_999]
+    _check(idx, X, Q, 8)
+    idx.close()
+
+
+@pytest.mark.parametrize("scale", [1e-4, 37.0, 2.5e4])
+def test_unnormalised_magnitudes(gpu_required, scale):
+    rng = np.random.default_rng(13)
+    X = (rng.standard_normal((50_000, 256)) * scale).astype(np.float32)
+    Q = (rng.standard_normal((16, 256)) * (1.0 / scale if scale > 1 else 3.0)).astype(np.float32)
+    for metric in (0, 1):
+        idx = _screened(X, metric)
+        _check(idx, X, Q, 10, metric)
+        assert idx.screen_stats()["max_err_ratio"] < 1.0
+        idx.close()
+
+
+def test_wide_dynamic_range_inside_rows(gpu_required):
+    # a few large coordinates and many tiny ones: elements below the fp16 range after scaling are
+    # covered by the bound's absolute term
+    rng = np.random.default_rng(14)
+    X = (rng.standard_normal((40_000, 128)) * 1e-6).astype(np.float32)
+    X[:, :4] = rng.standard_normal((40_000, 4)).astype(np.float32) * 50.0
+    Q = rng.standard_normal((8, 128)).astype(np.float32)
+    idx = _screened(X)
+    _check(idx, X, Q, 10)
+    assert idx.screen_stats()["max_err_ratio"] < 1.0
+    idx.close()
+
+
+def test_incremental_add_rescales_the_copy(gpu_required):
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, FlatIndex
+    rng = np.random.default_rng(15)
+    A = _unit(rng, 30_000, 384)
+    B = (_unit(rng, 20_000, 384) * 300.0).astype(np.float32)   # needs a new scale: everything is converted again
+    Cc = _unit(rng, 10_000, 384)
+    idx = FlatIndex(384)
+    idx.set_screening(SCREEN_FP16)            # enabled on an empty index
+    Q = _unit(rng, 32, 384)
+    idx.add(A)
+    _check(idx, A, Q, 10)
+    idx.add(B)
+    _check(idx, np.vstack([A, B]), Q, 10)
+    idx.add(Cc)
+    _check(idx, np.vstack([A, B, Cc]), Q, 10)
+    assert idx.screening == SCREEN_FP16
+    idx.close()
+
+
+def test_out_of_range_corpus_disables_screening_not_results(gpu_required):
+    from rag_inference_pipeline_amd.flat_index import SCREEN_INACTIVE
+    rng = np.random.default_rng(16)
+    X = _unit(rng, 10_000, 64)
+    X[17, 3] = 3e20                            # beyond the magnitudes the bound covers
+    Q = _unit(rng, 4, 64)
+    idx = _screened(X)
+    assert idx.screening == SCREEN_INACTIVE
+    _check(idx, X, Q, 10)
+    assert idx.screen_stats()["queries"] == 0  # answered by the fp32 scan
+    idx.close()
+
+
+def test_bad_queries_fall_back_per_query(gpu_required):
+    from rag_inference_pipeline_amd.flat_index import FlatIndex
+    rng = np.random.default_rng(17)
+    X = _unit(rng, 30_000, 128)
+    Q = _unit(rng, 6, 128)
+    Q[1] *= 1e15                               # out of range: that query alone goes to the fp32 scan
+    Q[4] = 0.0                                 # all-zero query: every score 0, ids 0..k-1
+    plain = FlatIndex(128)
+    plain.add(X)
+    want = plain.search(Q, 10)
+    idx = _screened(X)
+    got = idx.search(Q, 10)
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert got[1][4].tolist() == list(range(10))
+    st = idx.screen_stats()
+    assert st["fallbacks"] >= 1
+    plain.close()
+    idx.close()
+
+
+def test_screening_limits_and_switching_off(gpu_required):
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, SCREEN_OFF, FlatIndex
+    wide = FlatIndex(1030)
+    with pytest.raises(RuntimeError, match="two-stage search covers"):
+        wide.set_screening(SCREEN_FP16)
+    wide.close()
+    rng = np.random.default_rng(18)
+    X, Q = _unit(rng, 20_000, 384), _unit(rng, 32, 384)
+    idx = _screened(X)
+    _check(idx, X, Q, 150)                     # k beyond the two-stage range: plain fp32 rounds
+    assert idx.screen_stats()["queries"] == 0
+    _check(idx, X, Q, 10)
+    idx.set_screening(SCREEN_OFF)
+    assert idx.screening == SCREEN_OFF
+    _check(idx, X, Q, 10)
+    idx.close()
+
+
+def test_screened_device_api_and_id_offset(gpu_required):
+    import torch
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, FlatIndex
+    rng = np.random.default_rng(19)
+    X, Q = _unit(rng, 50_000, 768), _unit(rng, 32, 768)
+    idx = FlatIndex(768)
+    idx.add_device(torch.from_numpy(X).cuda().data_ptr(), len(X))
+    idx.set_id_offset(1_000_000)
+    idx.set_screening(SCREEN_FP16)
+    q = torch.from_numpy(Q).cuda()
+    D = torch.empty((32, 10), dtype=torch.float32, device="cuda")
+    I = torch.empty((32, 10), dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):                         # back-to-back searches share the workspace
+        idx.search_device(q.data_ptr(), 32, 10, D.data_ptr(), I.data_ptr(), st)
+    torch.cuda.synchronize()
+    Do, Io = oracle.search(X, Q, 10, 0, 1_000_000)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
+    idx.close()
