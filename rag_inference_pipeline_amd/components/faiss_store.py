@@ -32,6 +32,7 @@ from ..config import PipelineSettings
 logger = logging.getLogger(__name__)
 
 _ADD_CHUNK_ROWS = 1 << 18  # rows per host->device copy when loading a file
+_TWO_STAGE_MAX_D = 1024    # rag_index_set_screening covers d <= 1024
 
 
 class FAISSStore:
@@ -54,7 +55,7 @@ class FAISSStore:
             raise FileNotFoundError(f"FAISS index not found at {self.index_path}")
         logger.info("Loading FAISS index from %s", self.index_path)
         try:
-            from ..flat_index import FlatIndex  # raises if librag_amd.so is missing: no fallback
+            from ..flat_index import SCREEN_FP16, FlatIndex  # raises if librag_amd.so is missing: no fallback
 
             default_metric = index_io.metric_from_name(getattr(self.settings, "faiss_metric", "ip"))
             rows, metric = index_io.read_index_file(
@@ -75,6 +76,11 @@ class FAISSStore:
             for lo in range(row_lo, row_hi, _ADD_CHUNK_ROWS):
                 index.add(np.ascontiguousarray(rows[lo:min(lo + _ADD_CHUNK_ROWS, row_hi)], dtype=np.float32))
             index.set_id_offset(row_lo)
+            if bool(getattr(self.settings, "faiss_two_stage", True)) and d <= _TWO_STAGE_MAX_D:
+                index.set_screening(SCREEN_FP16)
+                if index.screening != SCREEN_FP16:
+                    logger.warning("two-stage search inactive: corpus values outside the range its error "
+                                   "bound covers; searches use the one-pass fp32 scan")
             self._index = index
             self._ntotal = n
             if world > 1:

@@ -69,6 +69,9 @@ class PipelineSettings(BaseModel):
     # "f16" = fp16-input GEMMs for the cross-encoder, the precision the reference uses on a GPU
     # (reranker.py:91-93); "f32" (default) matches the CPU path the parity tests are held to
     reranker_dtype: str = Field(default="f32", alias="RAG_AMD_RERANKER_DTYPE")
+    # two-stage exact search (include/rag_amd.h rag_index_set_screening): same results as the one-pass
+    # fp32 scan at about half the HBM traffic, for +50 % index memory; applies to d <= 1024, k <= 100
+    faiss_two_stage: bool = Field(default=True, alias="RAG_AMD_TWO_STAGE")
 
     @classmethod
     def from_env(cls, env: dict[str, str] | None = None, **overrides: Any) -> "PipelineSettings":
