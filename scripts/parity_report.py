@@ -17,6 +17,8 @@ ap.add_argument("--rows", type=int, default=1_000_000)
 ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--queries", type=int, default=64)
 ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--two-stage-queries", type=int, default=2048,
+                help="also compare the two-stage search with the one-pass search on this many extra queries")
 ap.add_argument("--json", default="")
 a = ap.parse_args()
 N, d, B, k = a.rows, a.dim, a.queries, a.k
@@ -25,6 +27,23 @@ idx = FlatIndex(d)
 idx.add_synthetic(N, 1234)
 Q = oracle.synth_rows(4321, 0, B, d)
 D, I = idx.search(Q, k)
+
+# two-stage search vs one-pass search on the same index: every id and every score bit must agree
+two_stage = None
+if a.two_stage_queries > 0 and d <= 1024 and k <= 100:
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, SCREEN_OFF
+    Q2 = oracle.synth_rows(777, 0, a.two_stage_queries, d)
+    Q2[1::2] = oracle.synth_rows(1234, 5, a.two_stage_queries, d)[1::2] + 0.05 * Q2[1::2]   # half near corpus rows
+    Q2 /= np.linalg.norm(Q2, axis=1, keepdims=True)
+    Q2 = np.vstack([Q, Q2]).astype(np.float32)
+    D1, I1 = idx.search(Q2, k)
+    idx.set_screening(SCREEN_FP16)
+    D2, I2 = idx.search(Q2, k)
+    st = idx.screen_stats()
+    idx.set_screening(SCREEN_OFF)
+    two_stage = {"queries": int(len(Q2)), "identical_ids": bool(np.array_equal(I1, I2)),
+                 "identical_score_bits": bool(np.array_equal(D1.view(np.uint32), D2.view(np.uint32))),
+                 "certificate_fallbacks": st["fallbacks"], "max_observed_error_over_bound": st["max_err_ratio"]}
 
 # float64 truth, streamed in chunks of rows regenerated on the CPU (bit-identical to the GPU corpus)
 top_s = np.full((B, k + 1), -np.inf)
@@ -65,8 +84,9 @@ for b in range(B):
 rep = {"rows": N, "dim": d, "queries": B, "k": k, "gpu_vs_oracle_bit_identical": bit_identical,
        "queries_identical_to_float64_ranking": exact_rows, "queries_differing_only_at_near_ties": near_tie_rows,
        "real_mismatches": real_mismatch, "near_tie_bound": noise, "max_abs_score_error_vs_float64": max_score_err,
-       "seconds_cpu": time.time() - t0}
+       "seconds_cpu": time.time() - t0, "two_stage_vs_one_pass": two_stage}
 print(json.dumps(rep))
 if a.json:
     json.dump(rep, open(a.json, "w"), indent=1)
 assert bit_identical and real_mismatch == 0 and max_score_err < 1e-4
+assert two_stage is None or (two_stage["identical_ids"] and two_stage["identical_score_bits"])
