@@ -141,6 +141,9 @@ struct ScanParams {
     int n_tiles;           // ceil(n_rows / 32)
     int n_iters;           // tiles per wave
     const uint32_t* enable;  // null, or a device word: 0 turns the whole launch into a no-op (fallback path)
+    const u64* thr_key;      // null, or [kQT] keys (0 = none) whose score >= k rows are known to reach (sample pass):
+                             // the filter starts there instead of at -inf
+    int tile_step;           // tile t covers rows [32 t tile_step, +32): 1 for a full scan, > 1 for the sample pass
     // screening pass (P == 1) only
     int kout;              // keys emitted per (query, workgroup), >= k
     const float* qscale;   // [kQT] power-of-two scale applied to a query before it is rounded to fp16
@@ -222,7 +225,12 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         cnt[tid] = 0;
         // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
         // they never enter the slow path (left at -inf they tie forever and double the scan time)
-        thr[tid] = tid < p.nq ? -__builtin_inff() : __builtin_inff();
+        float t0 = -__builtin_inff();
+        if (p.thr_key && tid < p.nq && p.thr_key[tid] != 0ull) {
+            t0 = unord32((uint32_t)(p.thr_key[tid] >> 32));
+            if (P == 1) t0 -= p.margin[tid];  // the band below an approximate score that k rows reach
+        }
+        thr[tid] = tid < p.nq ? t0 : __builtin_inff();
         if (P == 1) {
             mrg[tid] = tid < p.nq ? p.margin[tid] : 0.f;
             // a query the prep kernel ruled out (non-finite, out of range) is answered by the fallback
@@ -233,13 +241,14 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     __syncthreads();
 
     const long long last_row = p.n_rows - 1;
+    const long long tile_rows = (long long)kTileRows * p.tile_step;  // distance between consecutive tiles' first rows
     const int tiles_per_iter = gridDim.x * kScanWaves;
     int tile = blockIdx.x * kScanWaves + wave;
     auto row_ptr = [&](int t) -> const float* {
 #if defined(RAGK_ABLATE_L2_WINDOW)
         t &= 31;
 #endif
-        long long row = (long long)t * kTileRows + r;
+        long long row = (long long)t * tile_rows + r;
         row = row < last_row ? row : last_row;
         return p.X + row * p.row_stride + p.col0 + 4 * h;
     };
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         }
 
         // ---- ranking scores.  Lane (r, h): query r, tile rows (i&3) + 8(i>>2) + 4h.
-        const long long row0 = (long long)tile * kTileRows;
+        const long long row0 = (long long)tile * tile_rows;
         float sc[16];
         if (P == 1) {  // undo the power-of-two scales (exact)
             const float uns = p.unscale[r];
@@ -515,6 +524,27 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
             }
         }
     }
+}
+
+// ---- sample pass -> starting thresholds ----------------------------------------------------------
+// A cold scan starts every filter at -inf: each workgroup fills and compacts its buffers several times
+// before its thresholds bite (measured on 1.25M x 768: 40 us of a 0.71 ms scan at k = 10, 240 us of 0.91
+// ms at k = 100).  For larger k a sample pass first runs the scan kernel with k = 1 over 2048 tiles
+// spread evenly through the corpus (one per wave); this kernel then takes, per query, the k-th largest
+// of the n_lists workgroup maxima.  At least k distinct rows reach that score, so the final k-th best
+// does too, and the real scan may start its filter there (ScanParams.thr_key) without losing a row.
+__global__ __launch_bounds__(64) void sample_threshold_kernel(const u64* heads, int n_lists, int k, u64* thr_key) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    u64 kk[1][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int l = e * 64 + lane;
+        kk[0][e] = l < n_lists ? heads[(size_t)q * n_lists + l] : 0ull;
+    }
+    wave_sort_desc<4, 1>(kk, lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (e * 64 + lane == k - 1) thr_key[q] = kk[0][e];  // 0 when fewer than k lists hold a row
 }
 
 // ---- K2: merge ------------------------------------------------------------------------------
@@ -764,6 +794,7 @@ struct ScreenQueryState {   // per pass of <= 32 queries (device memory)
     float margin[kQT];      // 2 eps (4 eps for L2 ranking scores)
     uint32_t lossy[kQT];    // certificate void: out-of-range query, or a workgroup dropped part of the band
     uint32_t overflow[kQT]; // certificate void: the band did not fit the candidate list (screen_collect_kernel)
+    uint32_t sample_lossy[kQT];  // scratch for the sample pass (its lists only seed thresholds)
     uint32_t fallback[kQT]; // set by the finalize kernel: this query goes through the fp32 scan
     uint32_t any_fallback;  // the fallback launches read this word
     uint32_t pad[3];

@@ -174,6 +174,10 @@ struct rag_index {
     ragk::ScreenCounters* sctr = nullptr;
     float* cand_s = nullptr; long long* cand_i = nullptr; ragk::u64* cand_keys = nullptr; size_t cand_cap = 0;
 
+    // sample pass (starting thresholds for k >= kSampleMinK)
+    ragk::u64* sample_heads = nullptr;  // kQT x kSampleLists workgroup maxima
+    ragk::u64* thr_keys = nullptr;      // kQT
+
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -322,6 +326,37 @@ int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
     return RAG_OK;
 }
 
+// Sample pass (flat_kernels.hip.h, "sample pass -> starting thresholds"): the scan kernel with k = 1 over
+// kSampleLists * 8 tiles spread through the corpus, then the k-th largest workgroup maximum per query
+// into h->thr_keys.  `base` is the ScanParams of the real scan (same corpus view, metric, ceiling).
+constexpr int kSampleMinK = 32;        // below this the pass costs about what it saves
+constexpr int kSampleLists = 256;      // workgroups of the sample pass (<= 256: one sort of 4 keys per lane)
+constexpr long long kSampleMinTiles = 8LL * kSampleLists * 8;   // only when the corpus dwarfs the sample (>= 524k rows)
+
+int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_t lds, int nq, int k, hipStream_t st) {
+    using namespace ragk;
+    int rc;
+    if (!h->sample_heads && (rc = dev_alloc(&h->sample_heads, (size_t)kQT * kSampleLists))) return rc;
+    if (!h->thr_keys && (rc = dev_alloc(&h->thr_keys, (size_t)kQT))) return rc;
+    const int lists = std::min(h->n_cus, kSampleLists);
+    ScanParams ss = base;
+    ss.partial = h->sample_heads;
+    ss.k = 1;
+    ss.kout = 1;
+    ss.n_tiles = lists * 8;
+    ss.n_iters = 1;
+    ss.tile_step = (int)(base.n_tiles / ss.n_tiles);
+    ss.thr_key = nullptr;
+    ss.enable = nullptr;
+    if (ss.lossy) ss.lossy = h->sq->sample_lossy;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3(lists), dim3(8 * 64), lds, st, ss);
+    HIP_TRY(hipGetLastError());
+    sample_threshold_kernel<<<dim3(nq), dim3(64), 0, st>>>(h->sample_heads, lists, k, h->thr_keys);
+    HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 // One pass of <= 32 queries: scan + merge into out (device pointers, row stride k).
 // `ceil` (device, kQT keys, or null) restricts candidates to keys below it; `last_key` (device, kQT keys, or
 // null) receives each query's k-th key; results go to columns [0, k) of rows of `out_stride` elements.
@@ -358,25 +393,9 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         HIP_TRY(hipGetLastError());
     }
 
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = h->prof && !enable;
-    if (timed) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, st));
-    }
-    for (int col0 = 0; col0 < h->d8; col0 += dc_full) {
-        const int dc8 = std::min(dc_full, h->d8 - col0);
-        const int S = dc8 / 8;
-        int ring = pick_ring(S);
-#ifdef RAGK_TUNING
-        {   // tuning overrides (scripts/tune_scan.py builds a side library with -DRAGK_TUNING)
-            const int w = env_int("RAG_AMD_SCAN_WAVES", 0);
-            if (w == 8 || w == 12 || w == 16) waves = w;
-            const int rg = env_int("RAG_AMD_SCAN_RING", 0);
-            if (ring_ok(S, rg)) ring = rg;
-        }
-#endif
+    // larger k on a large corpus: seed the filters from a sample pass (not part of the timed scan launch)
+    const bool sampled = !enable && !chunked && k >= kSampleMinK && n_tiles_ll >= kSampleMinTiles;
+    auto make_params = [&](int col0, int dc8) {
         ScanParams sp;
         sp.X = h->X;
         sp.xnorm = h->xnorm;
@@ -397,9 +416,39 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.n_tiles = n_tiles;
         sp.n_iters = n_iters;
         sp.enable = enable;
+        sp.thr_key = sampled ? h->thr_keys : nullptr;
+        sp.tile_step = 1;
         sp.kout = k;
         sp.qscale = sp.unscale = sp.margin = nullptr;
         sp.lossy = nullptr;
+        return sp;
+    };
+    if (sampled) {
+        rc = run_sample_pass(h, make_params(0, h->d8), scan_fn(8, 64, pick_ring(h->d8 / 8), l2), scan_lds_bytes(h->d8, 64),
+                             nq, k, st);
+        if (rc) return rc;
+    }
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timed = h->prof && !enable;
+    if (timed) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    for (int col0 = 0; col0 < h->d8; col0 += dc_full) {
+        const int dc8 = std::min(dc_full, h->d8 - col0);
+        const int S = dc8 / 8;
+        int ring = pick_ring(S);
+#ifdef RAGK_TUNING
+        {   // tuning overrides (scripts/tune_scan.py builds a side library with -DRAGK_TUNING)
+            const int w = env_int("RAG_AMD_SCAN_WAVES", 0);
+            if (w == 8 || w == 12 || w == 16) waves = w;
+            const int rg = env_int("RAG_AMD_SCAN_RING", 0);
+            if (ring_ok(S, rg)) ring = rg;
+        }
+#endif
+        const ScanParams sp = make_params(col0, dc8);
         ScanFn fn = scan_fn(waves, cap, ring, l2);
         const size_t lds = scan_lds_bytes(dc8, cap);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -488,6 +537,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     HIP_TRY(hipGetLastError());
 
     // stage 1: screening scan over the fp16 copy (addresses in 4-byte units: 16 halves = 8 units per step)
+    const bool sampled = k >= kSampleMinK && n_tiles_ll >= kSampleMinTiles;
     ScanParams sp;
     sp.X = reinterpret_cast<const float*>(h->X16);
     sp.xnorm = h->xnorm;
@@ -508,12 +558,19 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.n_tiles = n_tiles;
     sp.n_iters = n_iters;
     sp.enable = nullptr;
+    sp.thr_key = nullptr;
+    sp.tile_step = 1;
     sp.kout = kp;
     sp.qscale = h->sq->qscale;
     sp.unscale = h->sq->unscale;
     sp.margin = h->sq->margin;
     sp.lossy = h->sq->lossy;
     const int S = h->d64 / 16;
+    if (sampled) {
+        rc = run_sample_pass(h, sp, screen_fn(64, S % 8 == 0 ? 8 : 4, l2), scan_lds_bytes(h->d64 / 2, 64), nb, k, st);
+        if (rc) return rc;
+        sp.thr_key = h->thr_keys;  // allocated by the first sample pass
+    }
     ScanFn fn = screen_fn(cap, S % 8 == 0 ? 8 : 4, l2);
     const size_t lds = scan_lds_bytes(h->d64 / 2, cap);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -653,7 +710,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.second);
         }
         void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev,
-                         h->X16, h->sc_stats, h->sq, h->sctr, h->cand_s, h->cand_i, h->cand_keys};
+                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr, h->cand_s, h->cand_i, h->cand_keys};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};

@@ -38,6 +38,9 @@ CASES = [
     (30_000, 384, 32, 300, 0),    # k > max_k(384) = 240 -> two rounds with a key ceiling
     (6_000, 768, 5, 250, 1),      # k > max_k(768) = 112 -> three rounds, L2
     (200, 768, 3, 150, 0),        # rounds run past the end of a tiny corpus (-1 padding)
+    (600_000, 64, 32, 100, 0),    # k >= 32 on a large corpus: thresholds seeded by the sample pass
+    (700_001, 40, 9, 40, 1),      # same, L2, ragged
+    (600_000, 64, 5, 300, 0),     # sample pass inside key-ceiling rounds
 ]
 
 

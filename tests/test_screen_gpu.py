@@ -47,6 +47,8 @@ CASES = [
     (20_000, 1024, 32, 10, 0),    # largest d the screen covers
     (20_000, 1000, 32, 60, 0),    # fallback needs rounds (k > max_k(1000) = 48) if it ever runs
     (33, 64, 32, 10, 0),          # fewer rows than candidates
+    (600_000, 64, 32, 100, 0),    # sample pass seeds the screening pass's band thresholds
+    (600_000, 64, 7, 33, 1),
     (5, 64, 2, 10, 0),            # k > N: -1 padding
 ]
 
