@@ -199,8 +199,19 @@ typedef struct rag_bert_config {
     int32_t head;          /* RAG_HEAD_* */
     int32_t n_labels;      /* classifier outputs (1 for the rerankers) */
     float ln_eps;
-    int32_t gemm_f16;      /* 1: big-batch GEMMs take fp16 inputs (fp32 accumulate), as the reference's GPU reranker; 0: fp32 */
+    int32_t gemm_mode;     /* RAG_GEMM_*: how big-batch (> 1024 tokens) GEMMs run */
 } rag_bert_config;
+
+/* RAG_GEMM_F32 (default): fp32 results.  Big-batch GEMMs run on the bf16 matrix cores with every fp32
+ *   operand split exactly into three bf16 terms and the six products of weight >= 2^-16 accumulated in
+ *   fp32 (error below the fp32 accumulation's own rounding; 2.7x the fp32 MFMA rate).  The library
+ *   builds the split weight images at rag_bert_create (+1.5x the GEMM weights' memory).
+ * RAG_GEMM_F16: big-batch GEMMs take fp16 inputs (fp32 accumulate) — the precision the reference runs
+ *   its reranker at on a GPU (reranker.py:91-93); the caller supplies fp16 weight copies.
+ * RAG_GEMM_F32_STRICT: every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32 chains). */
+#define RAG_GEMM_F32 0
+#define RAG_GEMM_F16 1
+#define RAG_GEMM_F32_STRICT 2
 
 /* Number of entries rag_bert_create expects in `weights` for a config:
  *   [0] word_emb [V][H]  [1] pos_emb [P][H]  [2] type_emb [Tv][H] (NULL if type_vocab == 0)
@@ -209,7 +220,7 @@ typedef struct rag_bert_config {
  *     qkv_w [3H][H] (q;k;v rows) qkv_b [3H]  attn_out_w [H][H] attn_out_b [H]  ln1_gamma ln1_beta
  *     ffn_in_w [I][H] ffn_in_b [I]  ffn_out_w [H][I] ffn_out_b [H]  ln2_gamma ln2_beta
  *   then, if head != RAG_HEAD_NONE: head_dense_w [H][H] head_dense_b [H] head_out_w [n_labels][H] head_out_b
- *   then, if gemm_f16: per layer 4 fp16 copies (qkv_w, attn_out_w, ffn_in_w, ffn_out_w), same shapes
+ *   then, if gemm_mode == RAG_GEMM_F16: per layer 4 fp16 copies (qkv_w, attn_out_w, ffn_in_w, ffn_out_w), same shapes
  * All fp32, torch.nn.Linear layout (W[out][in], row-major), device memory on `device`.  The library
  * does not copy them: the caller (PyTorch-ROCm tensors) keeps them alive until rag_bert_destroy. */
 int32_t rag_bert_weight_count(const rag_bert_config* cfg);

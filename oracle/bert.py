@@ -30,8 +30,11 @@ import torch
 import torch.nn.functional as F
 
 
+_DTYPE = [torch.float32]  # hidden_states(dtype=torch.float64) evaluates the same graph in double (accuracy arbiter)
+
+
 def _t(w: dict[str, np.ndarray], key: str) -> torch.Tensor:
-    return torch.from_numpy(np.ascontiguousarray(w[key], dtype=np.float32))
+    return torch.from_numpy(np.ascontiguousarray(w[key], dtype=np.float32)).to(_DTYPE[0])
 
 
 def _act(x: torch.Tensor, name: str) -> torch.Tensor:
@@ -46,12 +49,22 @@ def _act(x: torch.Tensor, name: str) -> torch.Tensor:
 
 @torch.no_grad()
 def hidden_states(cfg: Any, w: dict[str, np.ndarray], seqs: Sequence[Sequence[int]],
-                  type_seqs: Sequence[Sequence[int]] | None = None) -> list[np.ndarray]:
+                  type_seqs: Sequence[Sequence[int]] | None = None, dtype: torch.dtype = torch.float32
+                  ) -> list[np.ndarray]:
     """Last hidden state of every sequence ([len_s, hidden] each), HF BertModel semantics."""
+    _DTYPE[0] = dtype
+    try:
+        return _hidden_states(cfg, w, seqs, type_seqs)
+    finally:
+        _DTYPE[0] = torch.float32
+
+
+def _hidden_states(cfg: Any, w: dict[str, np.ndarray], seqs: Sequence[Sequence[int]],
+                   type_seqs: Sequence[Sequence[int]] | None = None) -> list[np.ndarray]:
     n, L = len(seqs), max(len(s) for s in seqs)
     ids = torch.zeros((n, L), dtype=torch.long)
     types = torch.zeros((n, L), dtype=torch.long)
-    mask = torch.zeros((n, L), dtype=torch.float32)
+    mask = torch.zeros((n, L), dtype=_DTYPE[0])
     for i, s in enumerate(seqs):
         ids[i, : len(s)] = torch.tensor(list(s), dtype=torch.long)
         mask[i, : len(s)] = 1.0
@@ -65,7 +78,7 @@ def hidden_states(cfg: Any, w: dict[str, np.ndarray], seqs: Sequence[Sequence[in
     H, heads = cfg.hidden, cfg.n_heads
     dh = H // heads
     x = F.layer_norm(x, (H,), _t(w, "emb_ln_g"), _t(w, "emb_ln_b"), cfg.ln_eps)
-    bias = (1.0 - mask)[:, None, None, :] * torch.finfo(torch.float32).min
+    bias = (1.0 - mask)[:, None, None, :] * torch.finfo(torch.float32).min  # fp32's lowest, in either dtype
     for l in range(cfg.n_layers):
         p = f"layer{l}."
         qkv = F.linear(x, _t(w, p + "qkv_w"), _t(w, p + "qkv_b"))

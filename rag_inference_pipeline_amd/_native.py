@@ -40,7 +40,7 @@ BERT_OUT_MEAN, BERT_OUT_CLS, BERT_OUT_LOGITS, BERT_OUT_PROBS, BERT_OUT_HIDDEN = 
 class BertConfigStruct(C.Structure):
     _fields_ = [(name, C.c_int32) for name in (
         "vocab_size", "hidden", "n_layers", "n_heads", "intermediate", "max_positions", "type_vocab",
-        "pos_offset", "act", "head", "n_labels")] + [("ln_eps", C.c_float), ("gemm_f16", C.c_int32)]
+        "pos_offset", "act", "head", "n_labels")] + [("ln_eps", C.c_float), ("gemm_mode", C.c_int32)]
 
 
 _lib = None

@@ -28,6 +28,7 @@ CANONICAL_LAYER_KEYS = ("qkv_w", "qkv_b", "attn_out_w", "attn_out_b", "ln1_g", "
                         "ffn_in_w", "ffn_in_b", "ffn_out_w", "ffn_out_b", "ln2_g", "ln2_b")
 HEAD_KEYS = ("head_dense_w", "head_dense_b", "head_out_w", "head_out_b")
 
+_GEMM_MODES = {"f32": 0, "f16": 1, "f32_strict": 2}  # RAG_GEMM_F32 / _F16 / _F32_STRICT
 _ACTS = {"gelu": _native.ACT_GELU, "gelu_new": _native.ACT_GELU_TANH, "gelu_pytorch_tanh": _native.ACT_GELU_TANH,
          "relu": _native.ACT_RELU}
 
@@ -47,7 +48,10 @@ class BertConfig:
     n_labels: int = 1
     ln_eps: float = 1e-12
     pooling: str = "mean"          # sentence-embedding pooling: "mean" | "cls"
-    gemm_dtype: str = "f32"        # "f16": big-batch GEMMs take fp16 inputs (the reference's GPU reranker precision)
+    # how big-batch GEMMs run (include/rag_amd.h RAG_GEMM_*): "f32" fp32 results on the bf16 matrix cores
+    # (exact three-way bf16 split, six products), "f16" fp16 inputs (the reference's GPU reranker
+    # precision), "f32_strict" everything on the fp32 MFMA
+    gemm_dtype: str = "f32"
     extra: dict[str, Any] = field(default_factory=dict)
 
     # -- the model families BASELINE.json names (architecture facts are upstream model cards) ------
@@ -91,10 +95,12 @@ class BertConfig:
     def to_struct(self) -> _native.BertConfigStruct:
         if self.act not in _ACTS:
             raise ValueError(f"unsupported activation {self.act!r}")
+        if self.gemm_dtype not in _GEMM_MODES:
+            raise ValueError(f"gemm_dtype must be one of {sorted(_GEMM_MODES)}, got {self.gemm_dtype!r}")
         head = {"none": _native.HEAD_NONE, "bert": _native.HEAD_BERT, "roberta": _native.HEAD_ROBERTA}[self.head]
         return _native.BertConfigStruct(self.vocab_size, self.hidden, self.n_layers, self.n_heads, self.intermediate,
                                         self.max_positions, self.type_vocab, self.pos_offset, _ACTS[self.act], head,
-                                        self.n_labels, self.ln_eps, 1 if self.gemm_dtype == "f16" else 0)
+                                        self.n_labels, self.ln_eps, _GEMM_MODES[self.gemm_dtype])
 
     def weight_shapes(self) -> dict[str, tuple[int, ...]]:
         H, I = self.hidden, self.intermediate
@@ -252,8 +258,8 @@ class BertModel:
                     t16 = self._tensors[f"layer{l}.{k}"].to(torch.float16).contiguous()
                     self._tensors[f"layer{l}.{k}.f16"] = t16
                     ptrs.append(t16.data_ptr())
-        elif cfg.gemm_dtype != "f32":
-            raise ValueError(f"gemm_dtype must be 'f32' or 'f16', got {cfg.gemm_dtype!r}")
+        elif cfg.gemm_dtype not in _GEMM_MODES:
+            raise ValueError(f"gemm_dtype must be one of {sorted(_GEMM_MODES)}, got {cfg.gemm_dtype!r}")
         table = (C.c_void_p * len(ptrs))(*ptrs)
         struct = cfg.to_struct()
         assert self._lib.rag_bert_weight_count(C.byref(struct)) == len(ptrs)

@@ -175,6 +175,79 @@ __device__ __forceinline__ void store_tile_rows(const f32x16& acc, int m, int n_
     }
 }
 
+// Epilogue of the 128 x 128 big-M kernels: through LDS, so that global memory sees whole rows.
+// store_tile_rows writes what a lane holds — 16 bytes of one token row per instruction, 64 rows per
+// wave-instruction, 4.6 KB apart: on M = 178k, N = 1152 those scattered stores cost 0.40 ms of a 1.29 ms
+// GEMM (measured by removing them).  Here the four waves park one 64-row half of the tile in LDS
+// (row stride 132 floats: conflict-free 16-byte writes), and every wave-instruction then moves two
+// complete 512-byte rows: bias / activation / residual are applied on that side, so the residual is
+// read coalesced as well.  `Cs` is LDS the K loop no longer needs (>= 64 * 132 floats); the caller
+// has passed a barrier since its last read.
+constexpr int WGLD = 132;
+__device__ __forceinline__ void store_wg_tile_128(const f32x16 (&acc)[2][2], float* Cs, int tid, int wm, int wn, int r,
+                                                  int h, int m0, int n0, int M, int N, const float* bias,
+                                                  const float* R, int ldr, float* C, int ldc, int act) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (a) __syncthreads();  // the first half has left LDS
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(&Cs[(wm * 32 + r) * WGLD + wn * 64 + b * 32 + 8 * g + 4 * h]) = v;
+            }
+        __syncthreads();
+        const int c4 = tid & 31;             // float4 column of the 128-wide tile row
+        const int n = n0 + 4 * c4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && n + 3 < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = (tid >> 5) + 8 * i;                        // 0..63: LDS row
+            const int m = m0 + (lr >> 5) * 64 + a * 32 + (lr & 31);   // its token row
+            if (m >= M || n >= N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lr * WGLD + 4 * c4]);
+            if (n + 3 < N) {
+                v += bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+                if (R) v += *reinterpret_cast<const f32x4*>(R + (size_t)m * ldr + n);
+                *reinterpret_cast<f32x4*>(C + (size_t)m * ldc + n) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < N) {
+                        float x = apply_act(v[e] + (bias ? bias[n + e] : 0.f), act);
+                        if (R) x += R[(size_t)m * ldr + n + e];
+                        C[(size_t)m * ldc + n + e] = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Big-M launches use a 1-D grid and this map from workgroup id to output tile.  Workgroups are dealt
+// round-robin to the 8 XCDs, each with its own 4 MB L2: with the plain (x = n tile, y = m tile) grid the
+// n tiles that share one 128-row slab of A land on eight different XCDs and A is fetched from memory
+// eight times (measured on M = 178k, N = 1152, K = 384: the kernel took 1.0 ms with its MFMAs removed).
+// Here XCD x owns m tiles x, x + 8, ... and sweeps all n tiles of one m tile before the next, so a slab
+// of A is read from HBM once and W (a few MB) stays in that XCD's L2.
+constexpr int kXcds = 8;
+__host__ __device__ inline int xcd_grid(int M, int N, int BM, int BN) {
+    const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    return (tm + kXcds - 1) / kXcds * kXcds * tn;
+}
+__device__ __forceinline__ bool xcd_tile(int M, int N, int BM, int BN, int& m0, int& n0) {
+    const int tn = (N + BN - 1) / BN;
+    const int id = blockIdx.x, xcd = id % kXcds, j = id / kXcds;
+    const int mt = (j / tn) * kXcds + xcd;
+    m0 = mt * BM;
+    n0 = (j % tn) * BN;
+    return m0 < M;
+}
+
 // ---- GEMM: C[M][N] = A[M][K] · W[N][K]ᵀ (+ bias[N]) (+ R[M][N]) (act) -------------------------------------
 // (64·TM) x (64·TN) x 32 tiles, 4 waves (2 x 2), each wave TM x TN MFMA tiles of 32 x 32:
 //   TM = TN = 2: 128 x 128 tiles for big M (cross-encoder: M = all tokens of all pairs);
@@ -206,7 +279,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if constexpr (TM * TN > 1) {  // big-M instantiation: 1-D XCD-aware grid
+        if (!xcd_tile(p.M, p.N, BM, BN, m0, n0)) return;
+    }
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const bool split = gridDim.z > 1;
@@ -355,7 +431,8 @@ __global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p)
     __shared__ __attribute__((aligned(16))) _Float16 Ws[128 * HLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    int m0, n0;
+    if (!xcd_tile(p.M, p.N, 128, 128, m0, n0)) return;
 
     // A staging: 128 rows x 16 float4 -> thread (row = tid/16 + 16 j, float4 col = tid%16), 8 passes
     // W staging: 128 rows x  8 f16x8  -> thread (row = tid/8  + 32 j, f16x8  col = tid%8),  4 passes
@@ -428,6 +505,190 @@ __global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p)
         for (int b = 0; b < 2; ++b)
             store_tile_rows(acc[a][b], m0 + wm * 64 + a * 32 + r, n0 + wn * 64 + b * 32, h, p.M, p.N, p.bias, p.R,
                             p.ldr, p.C, p.ldc, p.act, false);
+}
+
+// fp32-accurate GEMM on the bf16 matrix cores (default for big M).  gfx950 multiplies fp32 at 1/16 of
+// its bf16 rate, so an fp32 GEMM is MFMA-bound long before HBM matters.  Every fp32 value is the exact
+// sum of three bf16 numbers (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8
+// significand bits); a product a*w expands into nine bf16 products of which the six of weight >= 2^-16
+// are kept — hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid — each exact in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-24 of |a w|, i.e. below the rounding of
+// the fp32 accumulation itself (measured against float64 on 256x384x256: 2.6e-9 relative, a hundred
+// times smaller than an fp32 GEMM's own summation error).  Six bf16 MFMAs cover K = 16 in 192 cycles
+// where eight fp32 MFMAs need 512.
+// A is split while it is staged into LDS (VALU work issued between the MFMAs).  W is split once, at model
+// creation, into an image already in MFMA-fragment order: for the 32-row tile nt, K-step ks (16
+// columns) and plane pl, lane (r, h) finds its eight values W[32 nt + r][16 ks + 8 h ..] at
+// (((nt * K/16 + ks) * 3 + pl) * 64 + 32 h + r) * 8 — so every wave loads its W operands straight from
+// L2 into registers with one coalesced 1-KiB read per fragment and W never touches LDS (staging both
+// operands made the kernel LDS-bound: 36 KB of LDS traffic per wave per K-tile against 48 MFMAs).
+// 128 x 128 x 32 tiles, 4 waves (2 x 2) of 64 x 64; the A image is double-buffered (one barrier per
+// K-tile); LDS rows are 32 + 8 bf16 = 80 B (20-dword stride: the 16 lanes of a ds_read_b128 phase hit
+// 16 distinct 4-bank groups).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int XBK = 32, XLD = 40;
+// experiment-only switches (scripts/exp/gemm_x6_bench.hip; never defined in the product build)
+#if defined(RAGB_X6_NO_MFMA)
+#define RAGB_X6_MFMA(w, a, c) ([&] { asm volatile("" ::"v"(w), "v"(a)); return c; }())
+#else
+#define RAGB_X6_MFMA(w, a, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0)
+#endif
+
+__global__ void pack_x6_kernel(const float* W, int N, int K, int ldw, __bf16* out) {  // N % 32 == 0, K % 16 == 0
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
+    const float x = W[(size_t)n * ldw + k];
+    const __bf16 hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    const int nt = n >> 5, r = n & 31, ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    const size_t frag = ((size_t)nt * (K / 16) + ks) * 3;  // fragment index of plane 0
+    const size_t lane_off = (size_t)(32 * h + r) * 8 + j;
+    out[(frag + 0) * 512 + lane_off] = hi;
+    out[(frag + 1) * 512 + lane_off] = mid;
+    out[(frag + 2) * 512 + lane_off] = lo;
+}
+
+struct GemmX6Params {
+    const float* A;     // [M][lda] fp32
+    const __bf16* Wx;   // fragment-order split image (pack_x6_kernel)
+    const float* bias;
+    const float* R;
+    float* C;
+    int M, N, K;        // N % 32 == 0, K % 32 == 0
+    int lda, ldr, ldc;
+    int act;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_x6_kernel(const GemmX6Params p) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][3][128 * XLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!xcd_tile(p.M, p.N, 128, 128, m0, n0)) return;
+    const int nk = p.K / XBK, nks = p.K / 16;
+
+    // A staging: 128 rows x 8 float4 -> thread (row = tid/8 + 32 j, float4 col = tid%8), 4 passes
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const float* ag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int am = m0 + arow + 32 * j;
+        am = am < p.M ? am : p.M - 1;
+        ag[j] = p.A + (size_t)am * p.lda + acol;
+    }
+    // this wave's two 32-row W tiles (clamped inside the matrix; stores are guarded)
+    const bf16x8* wfrag[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int nt = (n0 >> 5) + wn * 2 + b;
+        nt = nt < (p.N >> 5) ? nt : (p.N >> 5) - 1;
+        wfrag[b] = reinterpret_cast<const bf16x8*>(p.Wx) + (size_t)nt * nks * 3 * 64 + lane;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    auto stage = [&](const f32x4 (&ra)[4], int buf, int j0, int j1) {  // split rows j0..j1-1 of this thread into LDS
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            bf16x4 hi, mid, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = ra[j][e];
+                hi[e] = (__bf16)x;
+                const float r1 = x - (float)hi[e];
+                mid[e] = (__bf16)r1;
+                lo[e] = (__bf16)(r1 - (float)mid[e]);
+            }
+            const int o = (arow + 32 * j) * XLD + acol;
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
+            *reinterpret_cast<bf16x4*>(&As[buf][1][o]) = mid;
+            *reinterpret_cast<bf16x4*>(&As[buf][2][o]) = lo;
+        }
+    };
+
+    f32x4 ra[4];
+    bf16x8 wr[2][3][2];  // [K-step of the tile][plane][n tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) wr[ks][pl][b] = wfrag[b][(size_t)(ks * 3 + pl) * 64];
+    stage(ra, 0, 0, 4);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + XBK);
+    }
+    __syncthreads();
+
+    // (W plane, A plane) of the six kept terms, smallest first; the four output tiles take turns so that
+    // dependent MFMAs on one accumulator are three instructions apart
+    constexpr int kTerm[6][2] = {{0, 2}, {2, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;  // block-uniform
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[cur][pl][(wm * 64 + a * 32 + r) * XLD + 16 * ks + 8 * h]);
+            // the next tile's A rows are split and written into the other buffer under this step's MFMAs
+#ifndef RAGB_X6_NO_STAGE
+            if (more) stage(ra, cur ^ 1, 2 * ks, 2 * ks + 2);
+#endif
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = RAGB_X6_MFMA(wr[ks][kTerm[t][0]][b], af[kTerm[t][1]][a], acc[a][b]);
+#ifndef RAGB_X6_NO_WLOAD
+            if (more) {  // this step's W registers are free once its MFMAs have issued: refill for the next tile
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        wr[ks][pl][b] = wfrag[b][(size_t)(((kt + 1) * 2 + ks) * 3 + pl) * 64];
+            }
+#endif
+        }
+        if (kt + 2 < nk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)(kt + 2) * XBK);
+        }
+        __syncthreads();
+    }
+#ifdef RAGB_X6_NO_STORE
+    {
+        float live = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) live += acc[a][b][i];
+        if (live != 12345.678f) return;
+    }
+#endif
+    // the loop's last barrier is behind every wave: the A image is free to carry the output tile
+    store_wg_tile_128(acc, reinterpret_cast<float*>(&As[0][0][0]), tid, wm, wn, r, h, m0, n0, p.M, p.N, p.bias, p.R,
+                      p.ldr, p.C, p.ldc, p.act);
 }
 
 // Small-M GEMM: 64 x 64 x 64 tiles, EIGHT waves.  Waves 0-3 (2 x 2 over the tile) multiply columns 0-31 of

@@ -19,7 +19,7 @@ constexpr int kPerLayer = 12;
 constexpr int kEmbEntries = 5;
 
 int f16_base(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
-int weight_count(const rag_bert_config& c) { return f16_base(c) + (c.gemm_f16 ? 4 * c.n_layers : 0); }
+int weight_count(const rag_bert_config& c) { return f16_base(c) + (c.gemm_mode == RAG_GEMM_F16 ? 4 * c.n_layers : 0); }
 
 int map_act(int act) {
     switch (act) {
@@ -38,6 +38,8 @@ struct rag_bert {
     int n_cus = 256;
     bool valu_attention = false;  // RAG_AMD_VALU_ATTENTION=1: the VALU attention kernel (A/B checks)
     std::vector<const float*> w;
+    // RAG_GEMM_F32: split-bf16 images of the four GEMM weights of every layer (pack_x6_kernel), owned here
+    std::vector<__bf16*> wx;
     hipStream_t stream = nullptr;
     std::mutex mu;
     // activation workspace, sized for ws_tokens tokens / ws_seqs sequences
@@ -100,14 +102,32 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
     return RAG_OK;
 }
 
+// The three forms a GEMM weight can take: fp32 (always), an fp16 copy (RAG_GEMM_F16, caller-supplied),
+// a split-bf16 image (RAG_GEMM_F32, built at create).
+struct WRef {
+    const float* w;
+    const _Float16* w16;
+    const __bf16* wx;
+};
+
 // Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip; big M
-// takes fp16 inputs when the model was created with gemm_f16 and an fp16 copy of W is supplied.
-int launch_gemm(const float* A, int lda, const float* W, const _Float16* W16, int ldw, const float* bias, const float* R,
+// runs on the bf16 matrix cores with fp32 accuracy (split-bf16 image), or takes fp16 inputs when the
+// model was created with RAG_GEMM_F16, or stays on the fp32 MFMA (RAG_GEMM_F32_STRICT).
+int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* bias, const float* R,
                 int ldr, float* C, int ldc, int M, int N, int K, int act, hipStream_t st) {
+    const float* W = Wr.w;
+    const _Float16* W16 = Wr.w16;
     if (M <= 0) return RAG_OK;
+    if (M > 1024 && Wr.wx && K % ragb::XBK == 0 && ldw == K) {
+        ragb::GemmX6Params g{A, Wr.wx, bias, R, C, M, N, K, lda, ldr, ldc, act};
+        dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);
+        ragb::gemm_nt_x6_kernel<<<grid, dim3(256), 0, st>>>(g);
+        RAGC_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
     if (M > 1024 && W16 && K % ragb::HBK == 0) {
         ragb::GemmF16Params g{A, W16, bias, R, C, M, N, K, lda, ldw, ldr, ldc, act};
-        dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+        dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);
         ragb::gemm_nt_f16_kernel<<<grid, dim3(256), 0, st>>>(g);
         RAGC_HIP_TRY(hipGetLastError());
         return RAG_OK;
@@ -119,7 +139,7 @@ int launch_gemm(const float* A, int lda, const float* W, const _Float16* W16, in
     g.act = act;
     g.k_per_split = K;
     if (M > 1024) {
-        dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+        dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);
         ragb::gemm_nt_kernel<2, 2><<<grid, dim3(256), 0, st>>>(g);
     } else {
         dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
@@ -136,10 +156,11 @@ int launch_gemm(const float* A, int lda, const float* W, const _Float16* W16, in
 // kMaxSplits * M * N floats) reduced by the LayerNorm kernel; big M: fused-epilogue GEMM into `part`,
 // then LayerNorm.
 constexpr int kMaxSplits = ragb::kMaxSplitK;
-int launch_gemm_ln(const float* A, int lda, const float* W, const _Float16* W16, int ldw, const float* bias, const float* R, float* part,
+int launch_gemm_ln(const float* A, int lda, const WRef& Wr, int ldw, const float* bias, const float* R, float* part,
                    const float* ln_g, const float* ln_b, float* y, int M, int N, int K, float eps, int n_cus,
                    hipStream_t st) {
     if (M <= 0) return RAG_OK;
+    const float* W = Wr.w;
     int splits = 1;
     if (M <= 1024) {
         // One wave multiplies one 32x32 output tile over its K range, and the chip has 4 * n_cus SIMDs:
@@ -159,7 +180,7 @@ int launch_gemm_ln(const float* A, int lda, const float* W, const _Float16* W16,
         }
     }
     if (splits == 1) {
-        int rc = launch_gemm(A, lda, W, W16, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
+        int rc = launch_gemm(A, lda, Wr, ldw, bias, R, N, part, N, M, N, K, ragb::ACT_NONE, st);
         if (rc) return rc;
         ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, 1, nullptr, nullptr, ln_g, ln_b, y, M, N, eps);
     } else {
@@ -221,10 +242,14 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     const dim3 mgrid((max_len + 31) / 32, heads, nseq);
     for (int l = 0; l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
-        const _Float16* const* lh = c.gemm_f16 ? reinterpret_cast<const _Float16* const*>(w + f16_base(c) + 4 * l) : nullptr;
-        auto w16 = [&](int i) -> const _Float16* { return lh ? lh[i] : nullptr; };
+        const _Float16* const* lh =
+            c.gemm_mode == RAG_GEMM_F16 ? reinterpret_cast<const _Float16* const*>(w + f16_base(c) + 4 * l) : nullptr;
+        const int wsrc[4] = {0, 2, 6, 8};  // qkv_w, attn_out_w, ffn_in_w, ffn_out_w in the layer's table
+        auto wref = [&](int i) -> WRef {
+            return WRef{lw[wsrc[i]], lh ? lh[i] : nullptr, h->wx.empty() ? nullptr : h->wx[(size_t)4 * l + i]};
+        };
         // QKV projection
-        rc = launch_gemm(h->x, H, lw[0], w16(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
+        rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
         if (rc) return rc;
         if (h->valu_attention) {
             if (dh == 32)
@@ -240,12 +265,12 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         RAGC_HIP_TRY(hipGetLastError());
         // attention output projection + residual + LayerNorm (x is both residual and destination:
         // each token's row is read and written by the same wave of the LayerNorm kernel)
-        rc = launch_gemm_ln(h->ctx, H, lw[2], w16(1), H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
+        rc = launch_gemm_ln(h->ctx, H, wref(1), H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
         // feed-forward: act(x W1ᵀ + b1) W2ᵀ + b2 + residual, LayerNorm
-        rc = launch_gemm(h->x, H, lw[6], w16(2), H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
+        rc = launch_gemm(h->x, H, wref(2), H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
         if (rc) return rc;
-        rc = launch_gemm_ln(h->ffn, I, lw[8], w16(3), I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
+        rc = launch_gemm_ln(h->ffn, I, wref(3), I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
     }
 
@@ -264,7 +289,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             const int total = nseq * H;
             gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
             RAGC_HIP_TRY(hipGetLastError());
-            rc = launch_gemm(h->pooled, H, hw[0], nullptr, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
+            rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
             if (rc) return rc;
             const bool probs = out_kind == RAG_BERT_OUT_PROBS;
             head_out_kernel<<<dim3(nseq, c.n_labels), dim3(64), 0, st>>>(h->pooled2, hw[2], hw[3], probs ? h->logits : out,
@@ -332,6 +357,32 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
     const char* va = getenv("RAG_AMD_VALU_ATTENTION");
     h->valu_attention = va && *va == '1';
+    if (c.gemm_mode == RAG_GEMM_F32) {
+        // split-bf16 images of the layer GEMM weights (read once, here: later in-place edits of the
+        // caller's tensors are not seen by the big-batch path)
+        const int H = c.hidden, I = c.intermediate;
+        const int shape[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};
+        const int wsrc[4] = {0, 2, 6, 8};
+        h->wx.assign((size_t)4 * c.n_layers, nullptr);
+        for (int l = 0; l < c.n_layers; ++l) {
+            for (int i = 0; i < 4; ++i) {
+                const int N = shape[i][0], K = shape[i][1];
+                __bf16* img = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&img), (size_t)N * K * 3 * sizeof(__bf16)) != hipSuccess) {
+                    rag_bert_destroy(h);
+                    return ragc_fail(RAG_ERR_OOM, "device allocation of the split-bf16 weight images failed");
+                }
+                h->wx[(size_t)4 * l + i] = img;
+                const long long total = (long long)N * K;
+                ragb::pack_x6_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream>>>(
+                    h->w[kEmbEntries + kPerLayer * l + wsrc[i]], N, K, K, img);
+            }
+        }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+            rag_bert_destroy(h);
+            return ragc_fail(RAG_ERR_HIP, "building the split-bf16 weight images failed");
+        }
+    }
     *out = h;
     return RAG_OK;
 }
@@ -345,6 +396,8 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
         void* ptrs[] = {h->x, h->y, h->qkv, h->ctx, h->ffn, h->pooled, h->pooled2, h->logits, h->probs,
                         h->ids_dev, h->types_dev, h->cu_dev, h->out_dev};
         for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        for (__bf16* p : h->wx)
             if (p) (void)hipFree(p);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }

@@ -68,7 +68,9 @@ def run(name, cfg, lens, out_kind, reps=10, cpu_sample=0, threads=16, gemm_dtype
     res = {"stage": name, "nseq": nseq, "tokens": T, "max_len": L, "ms_per_batch": ms, "gemm_gflop": gf / 1e9,
            "attention_gflop": attn_flops(cfg, lens) / 1e9, "gemm_tflops_end_to_end": gf / ms / 1e9,
            "frac_of_fp32_mfma_peak": gf / ms / 1e9 / FP32_MFMA_PEAK_TF, "sequences_per_s": nseq / ms * 1e3,
-           "dtype": "f32" if gemm_dtype == "f32" else "f16 GEMM inputs, f32 accumulate / softmax / LayerNorm"}
+           "dtype": {"f32": "f32 (big-batch GEMMs: exact 3-way bf16 split, 6 products, on the bf16 matrix cores)",
+                     "f32_strict": "f32 on the fp32 MFMA throughout",
+                     "f16": "f16 GEMM inputs, f32 accumulate / softmax / LayerNorm"}[gemm_dtype]}
     print(f"{name}: nseq={nseq} tokens={T} maxlen={L}: {ms:.3f} ms/batch  GEMM {gf/1e9:.1f} GFLOP -> {gf/ms/1e9:.1f} TF/s "
           f"(attn {res['attention_gflop']:.2f} GFLOP)  {nseq/ms*1e3:.0f} seq/s", flush=True)
     model.close()
@@ -95,6 +97,8 @@ if __name__ == "__main__":
         run("cross-encoder, ms-marco-MiniLM-L-6-v2 arch, 32 queries x 100 docs", BertConfig.ms_marco_minilm_l6(), pairs, _native.BERT_OUT_PROBS, reps=5, cpu_sample=200 * c, threads=threads),
         run("cross-encoder, ms-marco-MiniLM-L-6-v2 arch, 32 queries x 10 docs", BertConfig.ms_marco_minilm_l6(), pairs[:320], _native.BERT_OUT_PROBS, reps=5),
         run("cross-encoder, bge-reranker-base arch, 32 queries x 100 docs", BertConfig.bge_reranker_base(), pairs, _native.BERT_OUT_PROBS, reps=3, cpu_sample=100 * c, threads=threads),
+        run("cross-encoder (fp32 MFMA only), ms-marco-MiniLM-L-6-v2 arch, 32 x 100 docs", BertConfig.ms_marco_minilm_l6(), pairs, _native.BERT_OUT_PROBS, reps=5, gemm_dtype="f32_strict"),
+        run("cross-encoder (fp32 MFMA only), bge-reranker-base arch, 32 x 100 docs", BertConfig.bge_reranker_base(), pairs, _native.BERT_OUT_PROBS, reps=3, gemm_dtype="f32_strict"),
         run("cross-encoder (fp16 GEMM mode), ms-marco-MiniLM-L-6-v2 arch, 32 x 100 docs", BertConfig.ms_marco_minilm_l6(), pairs, _native.BERT_OUT_PROBS, reps=5, gemm_dtype="f16"),
         run("cross-encoder (fp16 GEMM mode), bge-reranker-base arch, 32 x 100 docs", BertConfig.bge_reranker_base(), pairs, _native.BERT_OUT_PROBS, reps=3, gemm_dtype="f16"),
     ]

@@ -128,3 +128,28 @@ def test_cross_encoder_fp16_gemm_mode_tracks_fp32_oracle(gpu_required):
     assert np.abs(got16 - want).max() < 3e-2 * max(1.0, np.abs(want).max())  # fp16 inputs: ~1e-3 relative per GEMM
     assert np.abs(got16 - want).max() > 0  # and it really is a different arithmetic
     np.testing.assert_allclose(probs16, obert.classify(cfg, w, seqs, types), atol=5e-3)
+
+
+def test_split_bf16_gemms_keep_fp32_accuracy(gpu_required):
+    """Default big-batch GEMMs run on the bf16 matrix cores (three-way exact split, six products):
+    hidden states must be as close to a float64 evaluation as the fp32-MFMA path is."""
+    import torch
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    w = random_weights(cfg, 9)
+    rng = np.random.default_rng(9)
+    seqs = _seqs(rng, rng.integers(24, 65, size=80), cfg.vocab_size)     # ~3500 tokens: big-M path
+    types = [[0] * 8 + [1] * (len(s) - 8) for s in seqs]
+    split = BertModel(cfg, w)
+    got_split = split.hidden_states(seqs, types)
+    split.close()
+    cfg_s = _small(BertConfig.ms_marco_minilm_l6())
+    cfg_s.gemm_dtype = "f32_strict"
+    strict = BertModel(cfg_s, w)
+    got_strict = strict.hidden_states(seqs, types)
+    strict.close()
+    want64 = np.concatenate(obert.hidden_states(cfg, w, seqs, types, dtype=torch.float64), axis=0)
+    e_split = np.abs(got_split - want64).max()
+    e_strict = np.abs(got_strict - want64).max()
+    assert e_strict < 2e-5 and e_split < 2e-5, (e_split, e_strict)
+    assert e_split < 3 * e_strict + 1e-6, (e_split, e_strict)            # same accuracy class as the fp32 MFMA
+    assert np.abs(got_split - got_strict).max() > 0                      # and it really is another arithmetic
