@@ -274,8 +274,9 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int NBUF = (TM * TN == 1) ? 2 : 1;  // small tiles double-buffer LDS: one barrier per K-tile
-    __shared__ __attribute__((aligned(16))) float As_[NBUF][BM * GLD];
-    __shared__ __attribute__((aligned(16))) float Ws_[NBUF][BN * GLD];
+    __shared__ __attribute__((aligned(16))) float smem_[NBUF * (BM + BN) * GLD];  // one block: the epilogue reuses it
+    float(*As_)[BM * GLD] = reinterpret_cast<float(*)[BM * GLD]>(smem_);
+    float(*Ws_)[BN * GLD] = reinterpret_cast<float(*)[BN * GLD]>(smem_ + NBUF * BM * GLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -395,13 +396,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
     }
 
     // epilogue: lane r is token row .. + r, registers hold 16 of the 32 output features of each tile
-    float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
+    if constexpr (TM == 2 && TN == 2) {  // big M (never split): whole rows through LDS
+        __syncthreads();
+        store_wg_tile_128(acc, smem_, tid, wm, wn, r, h, m0, n0, p.M, p.N, p.bias, p.R, p.ldr, p.C, p.ldc, p.act);
+    } else {
+        float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-            store_tile_rows(acc[a][b], m0 + wm * 32 * TM + a * 32 + r, n0 + wn * 32 * TN + b * 32, h, p.M, p.N,
-                            p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);
+            for (int b = 0; b < TN; ++b)
+                store_tile_rows(acc[a][b], m0 + wm * 32 * TM + a * 32 + r, n0 + wn * 32 * TN + b * 32, h, p.M, p.N,
+                                p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);
+    }
 }
 
 // Half-precision-input GEMM (opt-in, big M only): A is fp32 in memory and rounded to fp16 while it is
@@ -427,8 +433,9 @@ struct GemmF16Params {
 };
 
 __global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[128 * HLD];
-    __shared__ __attribute__((aligned(16))) _Float16 Ws[128 * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 smem_[2 * 128 * HLD];  // one block: the epilogue reuses it
+    _Float16* const As = smem_;
+    _Float16* const Ws = smem_ + 128 * HLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     int m0, n0;
@@ -499,12 +506,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f16_kernel(const GemmF16Params p)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[b], af[a], acc[a][b], 0, 0, 0);
         }
     }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-            store_tile_rows(acc[a][b], m0 + wm * 64 + a * 32 + r, n0 + wn * 64 + b * 32, h, p.M, p.N, p.bias, p.R,
-                            p.ldr, p.C, p.ldc, p.act, false);
+    __syncthreads();
+    store_wg_tile_128(acc, reinterpret_cast<float*>(smem_), tid, wm, wn, r, h, m0, n0, p.M, p.N, p.bias, p.R, p.ldr, p.C,
+                      p.ldc, p.act);
 }
 
 // fp32-accurate GEMM on the bf16 matrix cores (default for big M).  gfx950 multiplies fp32 at 1/16 of
