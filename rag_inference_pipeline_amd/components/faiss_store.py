@@ -26,7 +26,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .. import index_io
+from .. import _native, index_io
 from ..config import PipelineSettings
 
 logger = logging.getLogger(__name__)
@@ -77,10 +77,13 @@ class FAISSStore:
                 index.add(np.ascontiguousarray(rows[lo:min(lo + _ADD_CHUNK_ROWS, row_hi)], dtype=np.float32))
             index.set_id_offset(row_lo)
             if bool(getattr(self.settings, "faiss_two_stage", True)) and d <= _TWO_STAGE_MAX_D:
-                index.set_screening(SCREEN_FP16)
-                if index.screening != SCREEN_FP16:
-                    logger.warning("two-stage search inactive: corpus values outside the range its error "
-                                   "bound covers; searches use the one-pass fp32 scan")
+                try:  # an optimisation, never a reason not to serve: e.g. no room for the extra fp16 copy
+                    index.set_screening(SCREEN_FP16)
+                    if index.screening != SCREEN_FP16:
+                        logger.warning("two-stage search inactive: corpus values outside the range its error "
+                                       "bound covers; searches use the one-pass fp32 scan")
+                except _native.RagAmdError as exc:
+                    logger.warning("two-stage search not enabled (%s); searches use the one-pass fp32 scan", exc)
             self._index = index
             self._ntotal = n
             if world > 1:
