@@ -229,3 +229,49 @@ def test_screened_device_api_and_id_offset(gpu_required):
     np.testing.assert_array_equal(I.cpu().numpy(), Io)
     np.testing.assert_array_equal(D.cpu().numpy().view(np.uint32), Do.view(np.uint32))
     idx.close()
+
+
+def test_randomised_corpora_two_stage_matches_oracle(gpu_required):
+    """40 seeded random draws: shapes, metrics, and the data the certificate finds hard — tight
+    clusters (dense near-ties around rank k), exact duplicates, quantised coordinates, skewed scales."""
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16
+    rng = np.random.default_rng(20261005)
+    dims = [8, 24, 64, 100, 200, 384, 520, 768, 1024]
+    fallbacks = queries = 0
+    for trial in range(40):
+        d = int(rng.choice(dims))
+        N = int(rng.integers(1, 20_000 if d <= 384 else 8_000))
+        nq = int(rng.integers(1, 50))
+        k = int(rng.choice([1, 3, 10, 16, 17, 48, 49, 100]))
+        metric = int(rng.integers(0, 2))
+        kind = trial % 5
+        if kind == 0:    # plain Gaussian, random overall scale
+            X = rng.standard_normal((N, d), dtype=np.float32) * np.float32(rng.choice([1e-3, 1.0, 300.0]))
+        elif kind == 1:  # tight clusters: many rows within the band of each other
+            centres = rng.standard_normal((max(1, N // 200), d), dtype=np.float32)
+            X = centres[rng.integers(0, len(centres), size=N)] + np.float32(1e-3) * rng.standard_normal((N, d), dtype=np.float32)
+        elif kind == 2:  # exact duplicates
+            X = rng.standard_normal((N, d), dtype=np.float32)
+            X[N // 2:] = X[: N - N // 2]
+        elif kind == 3:  # coordinates on a coarse grid: exact score ties between different rows
+            X = rng.integers(-3, 4, size=(N, d)).astype(np.float32)
+        else:            # one dominant coordinate
+            X = rng.standard_normal((N, d), dtype=np.float32)
+            X[:, 0] *= 100.0
+        Q = rng.standard_normal((nq, d), dtype=np.float32)
+        if kind == 1:
+            Q = X[rng.integers(0, N, size=nq)] + np.float32(1e-2) * Q   # queries inside the clusters
+        idx = _screened(np.ascontiguousarray(X, dtype=np.float32), metric)
+        assert idx.screening == SCREEN_FP16
+        D, I = idx.search(np.ascontiguousarray(Q, dtype=np.float32), k)
+        Do, Io = oracle.search(X, Q, k, metric)
+        msg = f"trial {trial}: kind={kind} N={N} d={d} nq={nq} k={k} metric={metric}"
+        np.testing.assert_array_equal(I, Io, err_msg=msg)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32), err_msg=msg)
+        st = idx.screen_stats()
+        assert st["max_err_ratio"] < 1.0, msg
+        fallbacks += st["fallbacks"]
+        queries += st["queries"]
+        idx.close()
+    assert queries > 0 and fallbacks > 0      # the hard corpora did exercise the fallback ...
+    assert fallbacks < queries                # ... and the easy ones did not
