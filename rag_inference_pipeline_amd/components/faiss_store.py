@@ -134,10 +134,19 @@ class FAISSStore:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
-    def serve_forever(self) -> int:
-        """Ranks other than 0 of a sharded deployment: join the leader's searches until it unloads."""
+    @property
+    def shard_link(self):
+        """The serving channel of a sharded deployment (None on one GPU): what `Reranker.attach_shard_link`
+        takes so that rerank batches are split over the same ranks."""
+        return self._sharded
+
+    def serve_forever(self, reranker=None) -> int:
+        """Ranks other than 0 of a sharded deployment: join the leader's searches — and, when this
+        rank's loaded `reranker` is passed, its query-sharded rerank passes — until it unloads."""
         if not self._is_loaded or self._sharded is None:
             raise RuntimeError("FAISS index not loaded in sharded mode. Call load() first.")
+        if reranker is not None:
+            reranker.attach_shard_link(self._sharded)
         return self._sharded.follower_loop()
 
     def unload(self) -> None:

@@ -11,6 +11,11 @@ settings.truncate_length) -> classifier logit -> sigmoid -> stable descending so
 Differences, all on the side of the hardware: the pairs of a whole BATCH of queries go through one
 packed forward pass (the reference loops over queries, :303-306, and pads each to its longest pair);
 arithmetic is fp32 (the reference uses fp16 on a GPU, :91-93).
+
+Multi-GPU: with one process per GPU the batch is sharded BY QUERY — query i and its
+documents go to rank i mod G, every rank scores its share with its own copy of the model, the scores
+come back to rank 0.  No tensor collective is involved; the texts travel as one scatter and the scores
+as one gather over the serving channel of the sharded index (`attach_shard_link`).
 """
 
 from __future__ import annotations
@@ -37,6 +42,7 @@ class Reranker:
         self.model = None
         self._max_len = 512
         self._loaded = False
+        self._link = None  # sharded.ShardedFlatIndex serving channel when the batch is split over ranks
         logger.info("Reranker initialized (device: %s)", self.device)
 
     def load(self) -> None:
@@ -106,6 +112,51 @@ class Reranker:
         scores = self._score_pairs([query] * len(documents), [d.content for d in documents])
         return self._ranked(documents, scores, top_n)
 
+    # -- query-sharded scoring over the ranks of a process group ---------------------------------------
+    def attach_shard_link(self, link) -> None:
+        """Use `link` (the ShardedFlatIndex of this rank's FAISSStore: `store.shard_link`) to split
+        rerank batches over the group.  Rank 0 calls rerank_batch as before; the other ranks register
+        their side of the exchange and serve it from the store's follower loop."""
+        from ..sharded import OP_RERANK
+
+        self._link = link
+        if link is not None and link.rank != 0:
+            link.register_handler(OP_RERANK, self._follower_pass)
+
+    def _score_work(self, work: list[tuple[int, str, list[str]]]) -> list[tuple[int, list[float]]]:
+        flat_q = [q for _, q, docs in work for _ in docs]
+        flat_d = [d for _, _, docs in work for d in docs]
+        scores = self._score_pairs(flat_q, flat_d) if flat_d else []
+        out, pos = [], 0
+        for qi, _, docs in work:
+            out.append((qi, scores[pos:pos + len(docs)]))
+            pos += len(docs)
+        return out
+
+    def _follower_pass(self) -> None:
+        dist, group = self._link._dist, self._link.group
+        recv: list = [None]
+        dist.scatter_object_list(recv, None, src=0, group=group)
+        dist.gather_object(self._score_work(recv[0]), None, dst=0, group=group)
+
+    def _sharded_scores(self, queries: list[str], documents_batch: list[list[Document]]) -> list[list[float]]:
+        from ..sharded import OP_RERANK
+
+        link = self._link
+        dist, group, world = link._dist, link.group, link.world
+        parts = [[(qi, queries[qi], [d.content for d in documents_batch[qi]]) for qi in range(r, len(queries), world)]
+                 for r in range(world)]
+        link.leader_call(OP_RERANK)
+        recv: list = [None]
+        dist.scatter_object_list(recv, parts, src=0, group=group)
+        gathered: list = [None] * world
+        dist.gather_object(self._score_work(recv[0]), gathered, dst=0, group=group)
+        scores: list[list[float]] = [[] for _ in queries]
+        for part in gathered:
+            for qi, sc in part:
+                scores[qi] = sc
+        return scores
+
     def rerank_batch(self, queries: list[str], documents_batch: list[list[Document]],
                      top_n: int | None = None) -> list[list[RerankedDocument]]:
         if not self._loaded or self.model is None or self.tokenizer is None:
@@ -113,6 +164,9 @@ class Reranker:
         if len(queries) != len(documents_batch):
             raise ValueError(
                 f"Queries ({len(queries)}) and documents ({len(documents_batch)}) must have same length")
+        if self._link is not None and self._link.world > 1 and self._link.rank == 0 and len(queries) > 1:
+            per_query = self._sharded_scores(queries, documents_batch)
+            return [self._ranked(docs, sc, top_n) if docs else [] for docs, sc in zip(documents_batch, per_query)]
         flat_q = [q for q, docs in zip(queries, documents_batch) for _ in docs]
         flat_d = [d.content for docs in documents_batch for d in docs]
         scores = self._score_pairs(flat_q, flat_d) if flat_d else []

@@ -69,6 +69,15 @@ class RetrievalExecutor:
             capacity=self.settings.retrieval_cache_capacity, ttl=self.settings.cache_max_ttl,
             name="retrieval_faiss_cache")
         self._lock = threading.Lock()
+        self._shard_link_checked = False
+
+    def _attach_shard_link(self, reranker: Any) -> None:
+        """One process per GPU: rerank batches are split by query over the ranks that shard the index.
+        Checked at the first rerank, when the components' load hooks have run."""
+        self._shard_link_checked = True
+        link = getattr(self.registry.get("faiss_store"), "shard_link", None)
+        if link is not None and hasattr(reranker, "attach_shard_link"):
+            reranker.attach_shard_link(link)
 
     async def start(self) -> None:
         await self.scheduler.start()
@@ -153,6 +162,8 @@ class RetrievalExecutor:
         per_request = [self._to_retrieval_docs(docs, scores)
                        for docs, scores in zip(documents_batch, distances_batch)]
         if reranker:
+            if not self._shard_link_checked:
+                self._attach_shard_link(reranker)
             inputs = [[Document.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
                                                 category=d.category) for d in docs] for docs in per_request]
             reranked = reranker.rerank_batch([req.query for req in batch.requests], inputs)

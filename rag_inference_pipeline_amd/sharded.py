@@ -22,6 +22,9 @@ from typing import Any, Callable, Protocol
 import numpy as np
 
 
+OP_SHUTDOWN, OP_SEARCH, OP_RERANK = 0, 1, 2  # first word of the leader's request head
+
+
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     """Rows [lo, hi) owned by `rank`: contiguous, sizes differ by at most one row."""
     return n_total * rank // world, n_total * (rank + 1) // world
@@ -58,6 +61,7 @@ class ShardedFlatIndex:
         self._torch, self._dist = torch, dist
         self.local = local
         self.metric = int(metric)
+        self._handlers: dict[int, Callable[[], None]] = {}
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -136,10 +140,30 @@ class ShardedFlatIndex:
 
     # -- serving: rank 0 answers requests, the other ranks follow -------------------------------------
     # The reference's retrieval node is ONE process (uvicorn) calling index.search(); with the corpus
-    # split over G ranks, rank 0 keeps that role and ships each batch's (nq, k, queries) to the
-    # followers, which sit in follower_loop() and join every collective search.
+    # split over G ranks, rank 0 keeps that role.  Every request it serves starts with a 4-word head
+    # [op, nq, k, d] broadcast to the followers, which sit in follower_loop(): OP_SEARCH ships the batch
+    # and runs the collective search; other ops run a handler a component registered (the reranker's
+    # query-sharded pass, components/reranker.py); OP_SHUTDOWN ends the loop.
     def _ctl_device(self) -> Any:
         return self.device if self.backend == "nccl" else self._torch.device("cpu")
+
+    def _send_head(self, op: int, nq: int = 0, k: int = 0, d: int = 0) -> None:
+        head = self._torch.tensor([op, nq, k, d], dtype=self._torch.int64, device=self._ctl_device())
+        self._dist.broadcast(head, src=0, group=self.group)
+
+    def register_handler(self, op: int, fn: Callable[[], None]) -> None:
+        """Followers: run `fn()` when the leader announces `op` (fn performs the matching collectives)."""
+        if op in (OP_SHUTDOWN, OP_SEARCH):
+            raise ValueError(f"op {op} is reserved")
+        self._handlers[int(op)] = fn
+
+    def leader_call(self, op: int) -> None:
+        """Rank 0: put every follower into its handler for `op`; the caller then runs the same
+        collectives the handler runs."""
+        if self.rank != 0:
+            raise RuntimeError("leader_call() is for rank 0")
+        if self.world > 1:
+            self._send_head(int(op))
 
     def leader_search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
         """Rank 0: broadcast the batch, run the collective search, return the merged result."""
@@ -147,32 +171,34 @@ class ShardedFlatIndex:
             raise RuntimeError("leader_search() is for rank 0; other ranks run follower_loop()")
         torch, dist = self._torch, self._dist
         q = np.ascontiguousarray(queries, dtype=np.float32)
-        head = torch.tensor([q.shape[0], int(k), q.shape[1]], dtype=torch.int64, device=self._ctl_device())
-        dist.broadcast(head, src=0, group=self.group)
+        self._send_head(OP_SEARCH, q.shape[0], int(k), q.shape[1])
         qt = torch.from_numpy(q).to(self._ctl_device())
         dist.broadcast(qt, src=0, group=self.group)
         return self.search(q, k)
 
     def follower_loop(self) -> int:
-        """Ranks > 0: serve collective searches until the leader sends shutdown(); returns the number
-        of batches served."""
+        """Ranks > 0: serve the leader's requests until it sends shutdown(); returns the number served."""
         if self.rank == 0:
             raise RuntimeError("follower_loop() is for ranks other than 0")
         torch, dist = self._torch, self._dist
         served = 0
         while True:
-            head = torch.zeros(3, dtype=torch.int64, device=self._ctl_device())
+            head = torch.zeros(4, dtype=torch.int64, device=self._ctl_device())
             dist.broadcast(head, src=0, group=self.group)
-            nq, k, d = (int(v) for v in head.tolist())
-            if nq <= 0:
+            op, nq, k, d = (int(v) for v in head.tolist())
+            if op == OP_SHUTDOWN:
                 return served
-            qt = torch.empty((nq, d), dtype=torch.float32, device=self._ctl_device())
-            dist.broadcast(qt, src=0, group=self.group)
-            self.search(qt.cpu().numpy(), k)
+            if op == OP_SEARCH:
+                qt = torch.empty((nq, d), dtype=torch.float32, device=self._ctl_device())
+                dist.broadcast(qt, src=0, group=self.group)
+                self.search(qt.cpu().numpy(), k)
+            elif op in self._handlers:
+                self._handlers[op]()
+            else:
+                raise RuntimeError(f"follower received op {op} with no handler registered")
             served += 1
 
     def shutdown(self) -> None:
         """Rank 0: release the followers from follower_loop()."""
         if self.rank == 0 and self.world > 1:
-            head = self._torch.zeros(3, dtype=self._torch.int64, device=self._ctl_device())
-            self._dist.broadcast(head, src=0, group=self.group)
+            self._send_head(OP_SHUTDOWN)

@@ -99,3 +99,29 @@ def test_faiss_store_sharded_serving_mode(gpu_required, tmp_path):
         np.testing.assert_array_equal(lead[f"I{i}"], I)
         np.testing.assert_array_equal(lead[f"D{i}"], D)
     assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])
+
+
+@pytest.mark.gpu
+def test_reranker_shards_batches_by_query(gpu_required, tmp_path):
+    """SURVEY §8e, rerank row: with one process per GPU the rerank batch is split by query over the
+    ranks that shard the index; order and scores (to fp32 rounding) equal the one-process result, and rerank requests
+    interleave with searches on the same serving channel."""
+    from rag_inference_pipeline_amd import index_io
+    n, d, world = 5_000, 64, 3
+    path = tmp_path / "faiss_index.bin"
+    index_io.write_flat_index(path, oracle.synth_rows(1234, 0, n, d), 0)
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"rr{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_rerank_worker.py"), str(r), str(world), str(port), str(path), out, str(d)],
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lead = np.load(outs[0])
+    assert bool(lead["same_order"]) and float(lead["max_diff"]) < 1e-5, (lead["same_order"], lead["max_diff"])
+    assert bool(lead["search_same"]) and int(lead["n_lists"]) == 7
+    assert all(s <= 5 for s in lead["sizes"])
+    assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])      # search, rerank, search
