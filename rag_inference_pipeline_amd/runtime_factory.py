@@ -112,3 +112,24 @@ def build_registry_from_profile(settings: PipelineSettings, profile: ProfileFile
             aliases[alias] = target
             registry.register_alias(alias, target)
     return registry, profile, aliases
+
+
+def run_follower(settings: PipelineSettings, profile: ProfileFile | None = None,
+                 configs_dir: str | Path | None = None) -> int:
+    """Ranks other than 0 of a one-process-per-GPU deployment (no counterpart in the reference, which is
+    a single process): build the same profile, load the index shard (and the reranker, if the profile
+    has one) on this rank's GPU, then serve rank 0's searches and query-sharded rerank passes until it
+    unloads.  `torch.distributed` must already be initialised.  Returns the number of requests served."""
+    registry, _, _ = build_registry_from_profile(settings, profile, configs_dir)
+    store, reranker = registry.get("faiss_store"), registry.get("reranker")
+    if store is None:
+        raise RuntimeError("profile has no faiss store: nothing for a follower rank to serve")
+    store.load()
+    if reranker is not None:
+        reranker.load()
+    try:
+        return store.serve_forever(reranker=reranker)
+    finally:
+        if reranker is not None:
+            reranker.unload()
+        store.unload()
