@@ -98,11 +98,15 @@ class Reranker:
     def _ranked(documents: list[Document], scores: list[float], top_n: int | None) -> list[RerankedDocument]:
         # fields come from validated Document objects: skip a second validation pass (3200 documents
         # per batch at top-100 make it the largest host cost after tokenisation)
-        scored = [RerankedDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
-                                                   category=d.category, score=float(s))
-                  for d, s in zip(documents, scores)]
-        scored.sort(key=lambda x: x.score, reverse=True)  # stable: ties keep retrieval order
-        return scored[: len(documents) if top_n is None else top_n]
+        order = sorted(range(len(documents)), key=scores.__getitem__, reverse=True)  # stable: ties keep retrieval order
+        if top_n is not None:
+            order = order[:top_n]  # objects only for what is returned
+        out = []
+        for i in order:
+            d = documents[i]
+            out.append(RerankedDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
+                                                        category=d.category, score=float(scores[i])))
+        return out
 
     def rerank(self, query: str, documents: list[Document], top_n: int | None = None) -> list[RerankedDocument]:
         if not self._loaded or self.model is None or self.tokenizer is None:

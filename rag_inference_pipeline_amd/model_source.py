@@ -34,6 +34,20 @@ _PRESETS = {
 }
 
 
+class _PieceMemo(dict):
+    """piece -> id, computed on first sight (crc32 into the id range above the special tokens)."""
+
+    def __init__(self, first: int, span: int) -> None:
+        super().__init__()
+        self._first, self._span = first, span
+
+    def __missing__(self, piece: str) -> int:
+        pid = self._first + zlib.crc32(piece.encode("utf-8")) % self._span
+        if len(self) < 200_000:
+            self[piece] = pid
+        return pid
+
+
 class HashTokenizer:
     """Deterministic stand-in vocabulary for synthetic models: lower-cased word / punctuation
     pieces hashed (crc32) into the id range above the special tokens.  BERT-style framing
@@ -46,18 +60,15 @@ class HashTokenizer:
         self.roberta = roberta
         self.cls_id, self.sep_id, self.pad_id = (0, 2, 1) if roberta else (101, 102, 0)
         self._first = 1000 if vocab_size > 2000 else 8
-        self._memo: dict[str, int] = {}
+        self._memo = _PieceMemo(self._first, vocab_size - self._first)
 
     def _piece_id(self, piece: str) -> int:
-        pid = self._memo.get(piece)
-        if pid is None:
-            pid = self._first + zlib.crc32(piece.encode("utf-8")) % (self.vocab_size - self._first)
-            if len(self._memo) < 200_000:
-                self._memo[piece] = pid
-        return pid
+        return self._memo[piece]
 
     def _ids(self, text: str) -> list[int]:
-        return [self._piece_id(p) for p in self._piece.findall(text.lower())]
+        # dict.__getitem__ with __missing__: no Python-level call for pieces seen before (a rerank batch
+        # looks up ~80k pieces)
+        return list(map(self._memo.__getitem__, self._piece.findall(text.lower())))
 
     def encode_batch(self, texts: Sequence[str], max_length: int) -> tuple[list[list[int]], list[list[int]]]:
         ids = [[self.cls_id] + self._ids(t)[: max(0, max_length - 2)] + [self.sep_id] for t in texts]
