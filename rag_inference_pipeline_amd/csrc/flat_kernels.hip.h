@@ -698,7 +698,7 @@ __global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, co
 // Stage 1 (scan_topk_kernel<P = 1>) reads a scaled fp16 copy of the corpus — half the bytes of the
 // fp32 scan, and the matrix work drops to 1/16 — and keeps, per query and workgroup, every row whose
 // *approximate* score lies within 2 eps of the workgroup's running k-th best.  screen_collect_kernel
-// then gathers the rows within 2 eps of the global k-th best approximate score (at most k' of them),
+// then gathers the rows within 2 eps of the global k-th best approximate score (at most 239 of them),
 // and stage 2 recomputes their canonical fp32 scores and ranks them.  With |approx - exact| <= eps
 // for every row, the k rows with the best approximate scores have exact scores >= a_k - eps, so the
 // k-th exact score is >= a_k - eps, so every true top-k row has approx >= a_k - 2 eps: it is in the
@@ -794,6 +794,7 @@ struct ScreenQueryState {   // per pass of <= 32 queries (device memory)
     float margin[kQT];      // 2 eps (4 eps for L2 ranking scores)
     uint32_t lossy[kQT];    // certificate void: out-of-range query, or a workgroup dropped part of the band
     uint32_t overflow[kQT]; // certificate void: the band did not fit the candidate list (screen_collect_kernel)
+    uint32_t count[kQT];    // candidates collected (packed at the front of the list)
     uint32_t sample_lossy[kQT];  // scratch for the sample pass (its lists only seed thresholds)
     uint32_t fallback[kQT]; // set by the finalize kernel: this query goes through the fp32 scan
     uint32_t any_fallback;  // the fallback launches read this word
@@ -874,6 +875,7 @@ struct ScreenCandidates {
     float* approx;        // [kQT][kp] approximate ranking scores
     long long* rows;      // [kQT][kp] local row numbers, -1 = empty
     uint32_t* overflow;   // [kQT] certificate void: band wider than kp or cut short
+    uint32_t* count;      // [kQT] candidates written
 };
 
 template <int OWN>
@@ -946,7 +948,10 @@ __global__ __launch_bounds__(256) void screen_collect_kernel(const KeyListSrc sr
     __syncthreads();
     const uint32_t n = s_cnt;
     for (int i = (int)min(n, (uint32_t)kp) + tid; i < kp; i += 256) out.rows[(size_t)q * kp + i] = -1;
-    if (tid == 0) out.overflow[q] = (n >= (uint32_t)kp || s_cut) ? 1u : 0u;
+    if (tid == 0) {
+        out.overflow[q] = (n >= (uint32_t)kp || s_cut) ? 1u : 0u;
+        out.count[q] = min(n, (uint32_t)kp);
+    }
 }
 
 // Exact second stage: canonical fp32 score of candidate (q, j), as a ranking key (0 for an empty slot).
@@ -1033,14 +1038,16 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(const float* X, long 
     exact_keys[(size_t)q * kp + c0 + tid] = key;
 }
 
-// One wave per query: certificate, rank the exact keys, write the results.  kp <= 64 * E.
-template <int E>
+// One wave per query: certificate, rank the exact keys, write the results.  kp <= 256; the usual few
+// dozen candidates take the one-key-per-lane sort.
 __global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx, const long long* cand_rows,
                                                              const u64* exact_keys, const uint32_t* overflow, int kp,
                                                              int k, int l2, const float* qnorm, long long id_offset,
                                                              ScreenQueryState* qs, ScreenCounters* ctr, float* out_s,
                                                              long long* out_i) {
+    constexpr int E = 4;
     const int q = blockIdx.x, lane = threadIdx.x;
+    const uint32_t cnt = qs->count[q];  // wave-uniform
     u64 kk[1][E];
     float worst = 0.f;
     const float margin = qs->margin[q];
@@ -1049,7 +1056,7 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx
     for (int e = 0; e < E; ++e) {
         const int idx = e * 64 + lane;
         u64 key = 0ull;
-        if (idx < kp && cand_rows[(size_t)q * kp + idx] >= 0) {
+        if ((uint32_t)idx < cnt && cand_rows[(size_t)q * kp + idx] >= 0) {
             key = exact_keys[(size_t)q * kp + idx];
             const float ex = unord32((uint32_t)(key >> 32));
             const float err = fabsf(approx[(size_t)q * kp + idx] - ex) * (l2 ? 0.5f : 1.f);
@@ -1062,7 +1069,13 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx
     // belt and braces — no verified candidate shows an error beyond the bound the band was built from
     bool ok = qs->lossy[q] == 0 && overflow[q] == 0;
     if (ok && !(worst <= eps)) ok = false;  // also catches eps == 0 with any error, and NaN
-    wave_sort_desc<E, 1>(kk, lane);
+    if (cnt <= 64u) {
+        u64 k1[1][1] = {{kk[0][0]}};
+        wave_sort_desc<1, 1>(k1, lane);
+        kk[0][0] = k1[0][0];
+    } else {
+        wave_sort_desc<E, 1>(kk, lane);
+    }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = e * 64 + lane;

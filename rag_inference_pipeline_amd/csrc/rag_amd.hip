@@ -502,7 +502,10 @@ constexpr int kScreenMaxD64 = 1024;
 
 int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st) {
     using namespace ragk;
-    const int kp = k <= 16 ? 64 : (k <= 48 ? 128 : 240);
+    // candidate slots per query: always the most the finalize sort takes (empty slots cost nothing: the
+    // collect kernel packs candidates at the front, verify groups without one return at once), so a dense
+    // neighbourhood has to put 240 rows inside the band before the fp32 fallback is needed
+    const int kp = 240;
     const int cap = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
     const bool l2 = h->metric == RAG_METRIC_L2;
     const int waves = 8;
@@ -589,7 +592,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
 
     // the band below the k-th best approximate key of every query -> (approximate ranking score, local row)
     KeyListSrc src{h->partial, grid, kp};
-    ScreenCandidates cands{h->cand_s, h->cand_i, h->sq->overflow};
+    ScreenCandidates cands{h->cand_s, h->cand_i, h->sq->overflow, h->sq->count};
     const int look = merge_look(grid, kp, k);
     auto collect = grid <= 256 ? screen_collect_kernel<1> : (grid <= 512 ? screen_collect_kernel<2> : screen_collect_kernel<kMergeMaxOwned>);
     collect<<<dim3(nb), dim3(256), (size_t)grid * look * 8, st>>>(src, grid, k, kp, look, h->sq->margin, cands);
@@ -602,9 +605,8 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     screen_verify_kernel<<<dim3((kp + kVerifyRows - 1) / kVerifyRows, nb), dim3(64), vlds, st>>>(
         h->X, h->d8, h->xnorm, qp, h->d, h->d8, l2 ? 1 : 0, kp, h->cand_i, h->cand_keys);
     HIP_TRY(hipGetLastError());
-    auto fin = kp <= 64 ? screen_finalize_kernel<1> : (kp <= 128 ? screen_finalize_kernel<2> : screen_finalize_kernel<4>);
-    fin<<<dim3(nb), dim3(64), 0, st>>>(h->cand_s, h->cand_i, h->cand_keys, h->sq->overflow, kp, k, l2 ? 1 : 0, h->qnorm,
-                                       h->id_offset, h->sq, h->sctr, os, oi);
+    screen_finalize_kernel<<<dim3(nb), dim3(64), 0, st>>>(h->cand_s, h->cand_i, h->cand_keys, h->sq->overflow, kp, k,
+                                                          l2 ? 1 : 0, h->qnorm, h->id_offset, h->sq, h->sctr, os, oi);
     HIP_TRY(hipGetLastError());
 
     // fallback: the fp32 search of this block, enqueued unconditionally, a no-op unless a certificate failed
