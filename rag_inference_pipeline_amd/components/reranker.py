@@ -23,6 +23,7 @@ from __future__ import annotations
 import gc
 import logging
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 from ..bert import iter_token_budget
 from ..config import PipelineSettings
@@ -31,9 +32,14 @@ from .schemas import Document, RerankedDocument
 logger = logging.getLogger(__name__)
 
 _MAX_TOKENS_PER_PASS = 131072
+_PAIRS_PER_CHUNK = 640   # ~35 k tokens at the synthetic corpus' lengths: still the big-batch GEMM path
 
 
 class Reranker:
+    # rerank / rerank_batch read only doc_id, title, content and category of what they are given: callers
+    # may pass any row objects with those attributes (retrieval_executor.py does, to skip re-wrapping)
+    accepts_rows = True
+
     def __init__(self, settings: PipelineSettings) -> None:
         self.settings = settings
         self.model_name = settings.reranker_model_name
@@ -43,6 +49,7 @@ class Reranker:
         self._max_len = 512
         self._loaded = False
         self._link = None  # sharded.ShardedFlatIndex serving channel when the batch is split over ranks
+        self._tok_pool: ThreadPoolExecutor | None = None
         logger.info("Reranker initialized (device: %s)", self.device)
 
     def load(self) -> None:
@@ -75,6 +82,9 @@ class Reranker:
         logger.info("Unloading reranker model")
         if self.model is not None:
             self.model.close()
+        if self._tok_pool is not None:
+            self._tok_pool.shutdown(wait=True)
+            self._tok_pool = None
         self.model = None
         self.tokenizer = None
         gc.collect()
@@ -85,13 +95,29 @@ class Reranker:
         return self._loaded
 
     def _score_pairs(self, queries: list[str], docs: list[str]) -> list[float]:
+        """Sigmoid scores of (query, document) pairs.  Pairs go through in chunks: while the GPU scores one
+        chunk (the C call releases the GIL) a worker thread tokenises the next, so host tokenisation and
+        the cross-encoder pass overlap instead of adding up."""
         max_len = min(int(self.settings.truncate_length), self._max_len)
-        ids, types = self.tokenizer.encode_pairs(queries, docs, max_len)
-        use_types = types if self.model.cfg.type_vocab > 1 else None
+        with_types = self.model.cfg.type_vocab > 1
+        bounds = [(lo, min(lo + _PAIRS_PER_CHUNK, len(docs))) for lo in range(0, len(docs), _PAIRS_PER_CHUNK)]
+
+        def tokenise(lo: int, hi: int):
+            return self.tokenizer.encode_pairs(queries[lo:hi], docs[lo:hi], max_len)
+
         scores: list[float] = []
-        for lo, hi in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):
-            probs = self.model.classify(ids[lo:hi], use_types[lo:hi] if use_types is not None else None, sigmoid=True)
-            scores.extend(float(p) for p in probs[:, 0])
+        if not bounds:
+            return scores
+        if self._tok_pool is None:
+            self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rerank-tokenise")
+        pending = self._tok_pool.submit(tokenise, *bounds[0])
+        for i in range(len(bounds)):
+            ids, types = pending.result()
+            if i + 1 < len(bounds):
+                pending = self._tok_pool.submit(tokenise, *bounds[i + 1])
+            for lo, hi in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):
+                probs = self.model.classify(ids[lo:hi], types[lo:hi] if with_types else None, sigmoid=True)
+                scores.extend(probs[:, 0].tolist())
         return scores
 
     @staticmethod
@@ -105,7 +131,7 @@ class Reranker:
         for i in order:
             d = documents[i]
             out.append(RerankedDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
-                                                        category=d.category, score=float(scores[i])))
+                                                        category=d.category or "", score=float(scores[i])))
         return out
 
     def rerank(self, query: str, documents: list[Document], top_n: int | None = None) -> list[RerankedDocument]:

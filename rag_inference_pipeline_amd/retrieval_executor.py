@@ -159,16 +159,27 @@ class RetrievalExecutor:
         embeddings = self._get_embeddings(batch)
         doc_ids_batch, distances_batch = self._search(embeddings)
         documents_batch = self._fetch_documents(doc_ids_batch)
-        per_request = [self._to_retrieval_docs(docs, scores)
-                       for docs, scores in zip(documents_batch, distances_batch)]
         if reranker:
             if not self._shard_link_checked:
                 self._attach_shard_link(reranker)
-            inputs = [[Document.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
-                                                category=d.category) for d in docs] for docs in per_request]
+            # The reference wraps every fetched row three times on this path (RetrievalDocument -> Document ->
+            # RerankedDocument -> RetrievalDocument, api.py:475-514); at top-100 that is 12 800 pydantic
+            # objects per batch, more host time than the cross-encoder takes on the GPU.  A reranker that
+            # declares `accepts_rows` (this build's does) only reads doc_id / title / content / category and
+            # takes the fetched rows as they are, cut to the number of scores as the zip with the scores
+            # did; any other reranker gets the reference's Document objects.
+            if getattr(reranker, "accepts_rows", False):
+                inputs = [docs[:len(scores)] for docs, scores in zip(documents_batch, distances_batch)]
+            else:
+                inputs = [[Document.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
+                                                    category=d.category or "") for d, _ in zip(docs, scores)]
+                          for docs, scores in zip(documents_batch, distances_batch)]
             reranked = reranker.rerank_batch([req.query for req in batch.requests], inputs)
             per_request = [[RetrievalDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
-                                                              category=d.category, score=d.score) for d in docs]
+                                                              category=d.category or "", score=d.score) for d in docs]
                            for docs in reranked]
+        else:
+            per_request = [self._to_retrieval_docs(docs, scores)
+                           for docs, scores in zip(documents_batch, distances_batch)]
         return [RetrievalResponseItem(request_id=req.request_id, docs=docs, compressed_docs=None)
                 for req, docs in zip(batch.requests, per_request)]

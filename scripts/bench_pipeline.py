@@ -25,6 +25,7 @@ ap.add_argument("--rerank", action="store_true")
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--batches", type=int, default=10)
 ap.add_argument("--dtype", default="f32")
+ap.add_argument("--profile", action="store_true", help="cProfile one batch and print the top host functions")
 a = ap.parse_args()
 
 WORDS = ("retrieval augmented generation pipeline vector index query document embedding transformer attention "
@@ -81,3 +82,7 @@ for s, v in snap.items():
     acc += v["seconds"]
 print(f"   {'(rest: rerank + objects)':28s} {(el - acc) / a.batches * 1e3:8.2f} ms/batch")
 assert len(items) == 32 and len(items[0].docs) == a.k
+if a.profile:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); ex._process_batch_sync(mk()); pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
