@@ -243,6 +243,19 @@ int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* 
                             int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
                             void* stream);
 
+/* ---- `compressed` document payload (host side) ------------------------------------------- */
+
+/* LZ4 block compression of src[0, n) into dst (capacity cap >= rag_lz4_compress_bound(n) always
+ * suffices); returns the compressed size, or -1 if dst is too small.  Python wraps blocks in the LZ4
+ * frame format (rag_inference_pipeline_amd/lz4frame.py) — what the reference produces with
+ * lz4.frame.compress(msgspec.json.encode(docs)) (services/retrieval/api.py:516-523) and the
+ * generation node reads with lz4.frame.decompress (services/generation/service.py:429). */
+int64_t rag_lz4_compress_bound(int64_t n);
+int64_t rag_lz4_block_compress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap);
+
+/* xxHash32 (the LZ4 frame header checksum byte is (xxh32(descriptor, 0) >> 8) & 0xFF). */
+uint32_t rag_xxh32(const uint8_t* data, int64_t n, uint32_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,8 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
-_SOURCES = ["rag_amd.hip", "rag_bert.hip"]
-_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "rag_common.h"]
+_SOURCES = ["rag_amd.hip", "rag_bert.hip", "rag_lz4.cpp"]
+_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "rag_common.h", "rag_lz4.cpp"]
 
 RAG_OK = 0
 RAG_ERR_INVALID_ARG = 1
@@ -115,6 +115,9 @@ def _declare(lib: C.CDLL) -> None:
         "rag_index_profile_enable": (C.c_int, [vp, C.c_int32]),
         "rag_index_profile": (C.c_int, [vp, C.POINTER(C.c_double), i64p, C.c_int32]),
         "rag_index_max_k": (C.c_int32, [C.c_int32, C.c_int32]),
+        "rag_lz4_compress_bound": (C.c_int64, [C.c_int64]),
+        "rag_lz4_block_compress": (C.c_int64, [vp, C.c_int64, vp, C.c_int64]),
+        "rag_xxh32": (C.c_uint32, [vp, C.c_int64, C.c_uint32]),
         "rag_index_set_screening": (C.c_int, [vp, C.c_int32]),
         "rag_index_screening": (C.c_int32, [vp]),
         "rag_index_screen_stats": (C.c_int, [vp, i64p, i64p, C.POINTER(C.c_double), C.c_int32]),

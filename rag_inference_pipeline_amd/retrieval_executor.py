@@ -17,12 +17,15 @@ and yields one RetrievalResponseItem per request, in request order.  Semantics k
   * unless DISABLE_CACHE_FOR_PROFILING is set, index results are cached per embedding (api.py:392-425)
 What is different: rerank runs as ONE batched call over the whole batch (rerank_batch) instead of
 a thread pool of per-query calls (api.py:579-589) — the GPU cross-encoder batches all pairs.
-The `compressed` payload mode (lz4 of msgspec JSON, api.py:516-523) is wire format and not built.
+In `compressed` payload mode (api.py:516-523) the documents leave as an LZ4 frame of compact JSON —
+the bytes lz4.frame.decompress + msgspec.json.decode read back on the generation node
+(generation/service.py:429-431) — and `docs` is empty.
 """
 
 from __future__ import annotations
 
 import asyncio
+import json
 import hashlib
 import logging
 import threading
@@ -181,5 +184,15 @@ class RetrievalExecutor:
         else:
             per_request = [self._to_retrieval_docs(docs, scores)
                            for docs, scores in zip(documents_batch, distances_batch)]
+        if getattr(self.settings, "documents_payload_mode", "full") == "compressed":
+            from . import lz4frame  # native block compressor behind the standard frame format
+
+            return [RetrievalResponseItem.model_construct(
+                        request_id=req.request_id, docs=[],
+                        compressed_docs=lz4frame.compress(json.dumps(
+                            [{"doc_id": d.doc_id, "title": d.title, "content": d.content, "category": d.category,
+                              "score": d.score} for d in docs],
+                            separators=(",", ":"), ensure_ascii=False).encode("utf-8")))
+                    for req, docs in zip(batch.requests, per_request)]
         return [RetrievalResponseItem(request_id=req.request_id, docs=docs, compressed_docs=None)
                 for req, docs in zip(batch.requests, per_request)]

@@ -291,6 +291,40 @@ def test_executor_encode_path_and_rerank_replace_scores():
     assert items[0].docs[0].score == pytest.approx(1 / 3)
 
 
+def test_executor_compressed_payload_mode_is_an_lz4_frame_of_compact_json():
+    """api.py:516-523: docs leave as lz4.frame(msgspec JSON) and `docs` is empty; the frame must be what
+    generation/service.py:429-431 decodes (standard LZ4 frame, list of doc dicts in field order)."""
+    import json
+
+    from rag_inference_pipeline_amd import lz4frame
+    ex, _ = _executor({"faiss_store": _Index(), "embedding_generator": _Embedder(), "reranker": _Reranker()},
+                      DOCUMENTS_PAYLOAD_MODE="compressed")
+    items = ex._process_batch_sync(Batch(1, [_req(0), _req(1)]))
+    assert all(it.docs == [] and isinstance(it.compressed_docs, bytes) for it in items)
+    frame = items[0].compressed_docs
+    assert frame[:4] == bytes([0x04, 0x22, 0x4D, 0x18]) and frame[-4:] == b"\0\0\0\0"   # magic ... end mark
+    raw = lz4frame.decompress(frame)
+    assert raw.startswith(b'[{"doc_id":2,"title":"","content":"","category":"","score":')       # compact, field order
+    docs = json.loads(raw)
+    assert [d["doc_id"] for d in docs] == [2, 1, 0] and docs[0]["score"] == pytest.approx(1 / 3)
+
+
+def test_lz4_frame_round_trips_and_header_checksum():
+    import os
+
+    from rag_inference_pipeline_amd import lz4frame
+    rng = np.random.default_rng(0)
+    words = [b"retrieval", b"augmented", b"generation", b"pipeline", b"vector", b"index", b" ", b"\xc3\xa9"]
+    cases = [b"", b"a", b"abc" * 5, bytes(70_000), os.urandom(3000), b"".join(rng.choice(words, size=20_000)),
+             bytes(range(256)) * 40, b"x" * ((4 << 20) + 17)]       # the last one spans two blocks
+    for data in cases:
+        frame = lz4frame.compress(data)
+        assert frame[4:7] == bytes([0x60, 0x70, 0x73])      # FLG, BD, (xxh32(FLG BD) >> 8) & 0xFF
+        assert lz4frame.decompress(frame) == data
+    text = cases[5]
+    assert len(lz4frame.compress(text)) < len(text) // 2    # it does compress
+
+
 def test_executor_result_cache_hits_skip_the_index():
     index = _Index()
     ex, _ = _executor({"faiss_store": index}, DISABLE_CACHE_FOR_PROFILING="false")
