@@ -133,9 +133,9 @@ int32_t rag_index_max_k(int32_t d, int32_t nq);
  * candidates and ranks them, (3) checks per query a certificate that no row outside the candidate
  * list can reach the k-th exact score.  Queries that pass return exactly what the one-pass fp32
  * search returns (same ids, bit-identical scores); queries that fail are re-run through the fp32
- * scan on the device, so results never depend on the mode.  Applies to d <= 1024 with finite corpus
- * values of ordinary magnitude; otherwise the index reports RAG_SCREEN_INACTIVE and searches use the
- * fp32 scan.  (No counterpart in the reference: faiss IndexFlat has one code path.) */
+ * scan on the device, so results never depend on the mode.  Applies to d <= 2048 (k <= 48 beyond
+ * d = 1024, k <= 16 beyond 1536: the LDS budget) with finite corpus values of ordinary magnitude;
+ * otherwise the index reports RAG_SCREEN_INACTIVE and searches use the fp32 scan.  (No counterpart in the reference: faiss IndexFlat has one code path.) */
 #define RAG_SCREEN_OFF 0
 #define RAG_SCREEN_FP16 1
 #define RAG_SCREEN_INACTIVE 2   /* requested, but the corpus is outside what the error bound covers */

@@ -32,7 +32,7 @@ from ..config import PipelineSettings
 logger = logging.getLogger(__name__)
 
 _ADD_CHUNK_ROWS = 1 << 18  # rows per host->device copy when loading a file
-_TWO_STAGE_MAX_D = 1024    # rag_index_set_screening covers d <= 1024
+_TWO_STAGE_MAX_D = 2048    # rag_index_set_screening covers d <= 2048
 
 
 class FAISSStore:

@@ -70,7 +70,7 @@ class PipelineSettings(BaseModel):
     # (reranker.py:91-93); "f32" (default) matches the CPU path the parity tests are held to
     reranker_dtype: str = Field(default="f32", alias="RAG_AMD_RERANKER_DTYPE")
     # two-stage exact search (include/rag_amd.h rag_index_set_screening): same results as the one-pass
-    # fp32 scan at about half the HBM traffic, for +50 % index memory; applies to d <= 1024, k <= 100
+    # fp32 scan at about half the HBM traffic, for +50 % index memory; applies to d <= 2048, k <= 100
     faiss_two_stage: bool = Field(default=True, alias="RAG_AMD_TWO_STAGE")
 
     @classmethod

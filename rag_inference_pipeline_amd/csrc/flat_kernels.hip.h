@@ -808,24 +808,24 @@ struct ScreenCounters {     // cumulative, read back by rag_index_screen_stats
     uint32_t pad;
 };
 
-// One workgroup per query: norms -> scales and margins; clears the per-pass flags.  d <= 1024, so a
-// thread reads at most four elements and all of its loads are in flight together.
+// One workgroup per query: norms -> scales and margins; clears the per-pass flags.  d <= 2048, so a
+// thread reads at most eight elements and all of its loads are in flight together.
 __global__ __launch_bounds__(256) void screen_prep_kernel(const float* Q, int nq, int d, int d64, int l2, float x_absmax,
                                                           float x_normmax, float x_scale, ScreenQueryState* qs) {
     __shared__ float s_ss[4], s_am[4];
     const int tid = threadIdx.x, q = blockIdx.x;  // grid = kQT: every slot of the state is rewritten
     if (q == 0 && tid == 0) qs->any_fallback = 0;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (q < nq) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int c = tid + 256 * u;
             if (c < d) v[u] = Q[(size_t)q * d + c];
         }
     }
     float ss = 0.f, amax = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
         const float a = fabsf(v[u]);
         amax = (a <= 3.0e38f) ? fmaxf(amax, a) : __builtin_inff();  // NaN / inf poison the maximum
         ss = __builtin_fmaf(a, a, ss);
@@ -963,6 +963,9 @@ __host__ __device__ inline size_t verify_lds_bytes(int d8) {
     return ((size_t)kVerifyRows * (d8 + 4) + d8) * sizeof(float);
 }
 
+// DQ = ceil(d8 / 1024): a thread holds 32 float4 of candidate rows at a time, i.e. all eight rows of the
+// group for d <= 1024, four rows per pass for d <= 2048.
+template <int DQ>
 __global__ __launch_bounds__(64) void screen_verify_kernel(const float* X, long long row_stride, const float* xnorm,
                                                            const float* Q, int d, int d8, int l2, int kp,
                                                            const long long* cand_rows, u64* exact_keys) {
@@ -976,36 +979,40 @@ __global__ __launch_bounds__(64) void screen_verify_kernel(const float* X, long 
         if (tid < kVerifyRows && c0 + tid < kp) exact_keys[(size_t)q * kp + c0 + tid] = 0ull;
         return;
     }
-    const int d4 = d8 / 4;  // <= 256 (d <= 1024)
-    {   // all of a thread's row loads are issued before the first LDS store (one memory latency, not eight)
-        f32x4 v[kVerifyRows][4];
-        float qreg[16];
+    const int d4 = d8 / 4;  // <= 256 * DQ
+    constexpr int RP = kVerifyRows / DQ, NU = 4 * DQ;
+    {   // a pass's row loads are all issued before its first LDS store (one memory latency per pass)
+        float qreg[16 * DQ];
 #pragma unroll
-        for (int j = 0; j < kVerifyRows; ++j) {
-            const long long id = __shfl(my_id, j, 64);
-            const f32x4* src = reinterpret_cast<const f32x4*>(X + (id < 0 ? 0 : id) * row_stride);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = tid + 64 * u;
-                v[j][u] = (id >= 0 && c < d4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 16 * DQ; ++u) {
             const int c = tid + 64 * u;
             qreg[u] = c < d ? Q[(size_t)q * d + c] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < kVerifyRows; ++j) {
-            f32x4* dst = reinterpret_cast<f32x4*>(rows + (size_t)j * (d8 + 4));
+        for (int pass = 0; pass < DQ; ++pass) {
+            f32x4 v[RP][NU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = tid + 64 * u;
-                if (c < d4) dst[c] = v[j][u];
+            for (int j = 0; j < RP; ++j) {
+                const long long id = __shfl(my_id, pass * RP + j, 64);
+                const f32x4* src = reinterpret_cast<const f32x4*>(X + (id < 0 ? 0 : id) * row_stride);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = tid + 64 * u;
+                    v[j][u] = (id >= 0 && c < d4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                f32x4* dst = reinterpret_cast<f32x4*>(rows + (size_t)(pass * RP + j) * (d8 + 4));
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int c = tid + 64 * u;
+                    if (c < d4) dst[c] = v[j][u];
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 16 * DQ; ++u) {
             const int c = tid + 64 * u;
             if (c < d8) qv[c] = qreg[u];
         }

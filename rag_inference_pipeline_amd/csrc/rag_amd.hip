@@ -498,7 +498,15 @@ int search_exact_block(rag_index* h, const float* qp, int nb, int k, float* os, 
 // fp16 screening scan -> k' candidates -> canonical fp32 scores -> certificate; queries that fail it
 // are answered by the fallback launches of the fp32 scan (no-ops otherwise).
 constexpr int kScreenMaxK = 100;
-constexpr int kScreenMaxD64 = 1024;
+constexpr int kScreenMaxD64 = 2048;
+
+// LDS buffer capacity of the screening pass for (d64, k): the usual 64 / 128 / 256 by k, as long as it
+// fits beside the fp16 query image (64 bytes per column: d = 1536 leaves room for k <= 48, d = 2048 for
+// k <= 16); 0 = this (d, k) is answered by the fp32 scan.
+int screen_capacity(int d64, int k) {
+    const int cap = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
+    return ragk::scan_lds_bytes(d64 / 2, cap) <= 160 * 1024 ? cap : 0;
+}
 
 int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st) {
     using namespace ragk;
@@ -506,7 +514,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     // collect kernel packs candidates at the front, verify groups without one return at once), so a dense
     // neighbourhood has to put 240 rows inside the band before the fp32 fallback is needed
     const int kp = 240;
-    const int cap = k <= 16 ? 64 : (k <= 48 ? 128 : 256);
+    const int cap = screen_capacity(h->d64, k);
     const bool l2 = h->metric == RAG_METRIC_L2;
     const int waves = 8;
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
@@ -600,9 +608,9 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
 
     // stage 2: canonical fp32 scores of the candidates, certificate, results
     const size_t vlds = verify_lds_bytes(h->d8);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(screen_verify_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
-    screen_verify_kernel<<<dim3((kp + kVerifyRows - 1) / kVerifyRows, nb), dim3(64), vlds, st>>>(
+    auto verify = h->d8 <= 1024 ? screen_verify_kernel<1> : screen_verify_kernel<2>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
+    verify<<<dim3((kp + kVerifyRows - 1) / kVerifyRows, nb), dim3(64), vlds, st>>>(
         h->X, h->d8, h->xnorm, qp, h->d, h->d8, l2 ? 1 : 0, kp, h->cand_i, h->cand_keys);
     HIP_TRY(hipGetLastError());
     screen_finalize_kernel<<<dim3(nb), dim3(64), 0, st>>>(h->cand_s, h->cand_i, h->cand_keys, h->sq->overflow, kp, k,
@@ -632,7 +640,8 @@ int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float*
         HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    const bool screened = h->screen_on && h->screen_valid && k <= kScreenMaxK && h->d64 <= kScreenMaxD64;
+    const bool screened = h->screen_on && h->screen_valid && k <= kScreenMaxK && h->d64 <= kScreenMaxD64 &&
+                          screen_capacity(h->d64, k) > 0;
     for (int q0 = 0; q0 < nq; q0 += ragk::kQT) {
         const int nb = std::min(ragk::kQT, nq - q0);
         const float* qp = q_dev + (size_t)q0 * h->d;

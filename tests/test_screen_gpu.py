@@ -44,7 +44,10 @@ CASES = [
     (50_000, 384, 5, 100, 1),
     (30_000, 100, 32, 10, 0),     # d padded to 128 in the fp16 copy
     (30_000, 200, 3, 20, 1),      # padded to 256, ring of 4
-    (20_000, 1024, 32, 10, 0),    # largest d the screen covers
+    (20_000, 1024, 32, 10, 0),
+    (20_000, 1536, 32, 10, 0),    # d > 1024: the verify kernel takes its rows in two passes
+    (8_000, 1536, 5, 48, 1),      # largest k the LDS budget leaves at d = 1536
+    (10_000, 2048, 9, 16, 0),     # largest d the screen covers
     (20_000, 1000, 32, 60, 0),    # fallback needs rounds (k > max_k(1000) = 48) if it ever runs
     (33, 64, 32, 10, 0),          # fewer rows than candidates
     (600_000, 64, 32, 100, 0),    # sample pass seeds the screening pass's band thresholds
@@ -193,10 +196,18 @@ def test_bad_queries_fall_back_per_query(gpu_required):
 
 def test_screening_limits_and_switching_off(gpu_required):
     from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, SCREEN_OFF, FlatIndex
-    wide = FlatIndex(1030)
+    wide = FlatIndex(2100)
     with pytest.raises(RuntimeError, match="two-stage search covers"):
         wide.set_screening(SCREEN_FP16)
     wide.close()
+    rng = np.random.default_rng(180)
+    X, Q = _unit(rng, 6_000, 1536), _unit(rng, 8, 1536)
+    idx = _screened(X)
+    _check(idx, X, Q, 100)                     # k = 100 does not fit beside a 1536-wide query image: fp32 scan
+    assert idx.screen_stats()["queries"] == 0
+    _check(idx, X, Q, 20)
+    assert idx.screen_stats()["queries"] == 8
+    idx.close()
     rng = np.random.default_rng(18)
     X, Q = _unit(rng, 20_000, 384), _unit(rng, 32, 384)
     idx = _screened(X)
