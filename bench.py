@@ -308,6 +308,9 @@ def main() -> None:
                             f"({n_local} rows on rank 0), batch {B} precomputed unit-norm query embeddings "
                             "resident in HBM (configs/retrieval_faiss_only.yaml path)"
                             + ("; per-shard top-k merged by one RCCL all-gather + device merge" if world > 1 else ""),
+                "note": "value = the one-pass fp32 scan (the path SURVEY 8(d) defines the roofline on); "
+                        "two_stage_exact = the same step through the optional exact two-stage search "
+                        "(same ids and score bits), reported beside it",
                 "rows": N, "dim": d, "batch": B, "k": k, "rows_per_gpu": n_local,
                 "parallelism": f"corpus-shard x{world}",
             },
