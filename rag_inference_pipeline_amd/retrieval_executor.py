@@ -48,11 +48,17 @@ logger = logging.getLogger(__name__)
 
 
 def extract_embeddings_from_requests(requests: Sequence[Any]) -> np.ndarray:
+    """(batch, d) float32 from the requests' precomputed embeddings: the binary form (`embedding_f32`,
+    little-endian fp32 bytes) when a request carries it, else the reference's list of floats."""
     rows = []
     for req in requests:
-        if req.embedding is None:
+        raw = getattr(req, "embedding_f32", None)
+        if raw is not None:
+            rows.append(np.frombuffer(raw, dtype="<f4"))
+        elif req.embedding is not None:
+            rows.append(req.embedding)
+        else:
             raise ValueError("Missing embedding in batch")
-        rows.append(req.embedding)
     return np.array(rows).astype("float32")
 
 
@@ -90,7 +96,7 @@ class RetrievalExecutor:
 
     async def process_request(self, item: RetrievalRequestItem) -> RetrievalResponseItem:
         req = PendingRequest(request_id=item.request_id, query=item.query, embedding=item.embedding,
-                             timestamp=time.time())
+                             embedding_f32=getattr(item, "embedding_f32", None), timestamp=time.time())
         return await self.scheduler.enqueue(req)
 
     async def _process_batch(self, batch: Batch[RetrievalResponseItem]) -> list[RetrievalResponseItem]:
@@ -99,7 +105,8 @@ class RetrievalExecutor:
 
     # -- stages -------------------------------------------------------------------------------
     def _get_embeddings(self, batch: Batch[RetrievalResponseItem]) -> np.ndarray:
-        if batch.requests[0].embedding is not None:
+        first = batch.requests[0]
+        if first.embedding is not None or getattr(first, "embedding_f32", None) is not None:
             return extract_embeddings_from_requests(batch.requests)
         embedder = self.registry.get("embedding_generator")
         if not embedder:

@@ -291,6 +291,22 @@ def test_executor_encode_path_and_rerank_replace_scores():
     assert items[0].docs[0].score == pytest.approx(1 / 3)
 
 
+def test_executor_accepts_binary_embeddings():
+    """Optional wire form of a precomputed embedding: little-endian fp32 bytes (base64 in JSON)."""
+    import base64
+
+    from rag_inference_pipeline_amd.schemas import RetrievalRequestItem
+    index = _Index()
+    ex, _ = _executor({"faiss_store": index})
+    e0, e1 = np.arange(4, dtype=np.float32), np.arange(4, dtype=np.float32) * 0.5 + 1
+    item = RetrievalRequestItem(request_id="r0", query="q", embedding_f32=base64.b64encode(e0.tobytes()).decode())
+    assert item.embedding_f32 == e0.tobytes()                      # base64 text is decoded on validation
+    reqs = [PendingRequest(request_id="r0", query="q", embedding_f32=e0.tobytes(), timestamp=0.0),
+            PendingRequest(request_id="r1", query="q", embedding=e1.tolist(), timestamp=0.0)]   # forms may mix
+    ex._process_batch_sync(Batch(1, reqs))
+    np.testing.assert_array_equal(index.calls[0][0], np.stack([e0, e1]))
+
+
 def test_executor_compressed_payload_mode_is_an_lz4_frame_of_compact_json():
     """api.py:516-523: docs leave as lz4.frame(msgspec JSON) and `docs` is empty; the frame must be what
     generation/service.py:429-431 decodes (standard LZ4 frame, list of doc dicts in field order)."""
