@@ -155,7 +155,7 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
     CK(hipMalloc(&R, (size_t)M * N * 4)); CK(hipMalloc(&b, (size_t)N * 4));
     fill(A, (size_t)M * K); fill(W, (size_t)N * K); fill(R, (size_t)M * N); fill(b, N);
     ragb::GemmParams g{A, W, b, res ? R : nullptr, C, M, N, K, K, K, N, N, act, K};
-    dim3 grid((N + 127) / 128, (M + 127) / 128, 1);
+    dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);  // gemm_nt_kernel<2,2> takes the 1-D XCD-aware grid
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0));
