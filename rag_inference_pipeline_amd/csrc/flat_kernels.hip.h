@@ -10,7 +10,9 @@
 //                        compacted by a wave-level bitonic sort when one overflows.
 // K2  tournament_merge_kernel  per query: top-k of the sorted per-workgroup (or per-shard) lists by a
 //                        k-round workgroup-wide max tournament; decodes keys into (score, id).
-// plus small helpers (row norms, query norms, synthetic corpus, neutral fill).
+// K1' scan_topk_kernel<P = 1> + screen_* kernels  the optional two-stage exact search: fp16 screening pass,
+//                        candidate collection, canonical fp32 re-scoring, certificate, fp32 fallback.
+// plus small helpers (sample pass thresholds, row norms, synthetic corpus, neutral fill).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -551,9 +553,9 @@ __global__ __launch_bounds__(64) void sample_threshold_kernel(const u64* heads, 
 // Top-k of n_lists lists that are each sorted best-first (the per-workgroup lists K1 emits, or the
 // per-shard lists after the all-gather).  One 256-thread workgroup per query plays a k-round
 // tournament: every thread holds the head of the list(s) it owns, a round is one workgroup-wide
-// 64-bit max (shuffles + 4 LDS words), the winner advances its list.  ~150 cycles per round, so
-// k = 10 over 256 lists costs about a microsecond of device time — the bitonic merge this replaces
-// sorted 4096 keys to keep 10 and took 90.
+// 64-bit max (DPP reduction + 4 LDS words + one barrier), the winner advances its list.  A round is a
+// serial chain of wave-wide instructions, ~0.4 us: k = 10 over 256 lists takes ~9 us with the staging
+// and the launch — the bitonic merge this replaces sorted 4096 keys to keep 10 and took 90.
 constexpr int kMergeMaxOwned = 8;  // lists per thread: n_lists <= 2048
 
 struct KeyListSrc {  // lists of ranking keys: keys[(q * n_lists + l) * k + pos]
