@@ -1,0 +1,79 @@
+"""Worker: the serving channel on CPU — rank 0 leads searches and query-sharded rerank passes, the other
+ranks sit in follower_loop(); gloo, no GPU.  The local index is an ORACLE-backed test double and the
+reranker's model is a stub that scores a pair by its token count, so only the host logic, the op
+dispatch and the object collectives are exercised."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    n, d = 3001, 32
+    import torch
+    import torch.distributed as dist
+
+    from oracle import flat as oracle
+    from rag_inference_pipeline_amd.components.reranker import Reranker
+    from rag_inference_pipeline_amd.components.schemas import Document
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    from rag_inference_pipeline_amd.model_source import HashTokenizer
+    from rag_inference_pipeline_amd.sharded import ShardedFlatIndex, shard_range
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_range(n, rank, world)
+    X_local = oracle.synth_rows(1234, lo, hi - lo, d)
+
+    class OracleLocal:
+        def search_device(self, q_ptr, nq_, k_, s_ptr, i_ptr, stream=0):
+            q = np.ctypeslib.as_array(ctypes.cast(q_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, d))
+            D, I = oracle.search(X_local, q, k_, 0, id_offset=lo)
+            np.ctypeslib.as_array(ctypes.cast(s_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, k_))[:] = D
+            np.ctypeslib.as_array(ctypes.cast(i_ptr, ctypes.POINTER(ctypes.c_int64)), (nq_, k_))[:] = I
+
+    def merge(metric_, all_s, all_i, out_s, out_i):
+        D, I = oracle.merge(all_s.numpy(), all_i.numpy(), metric_)
+        out_s.copy_(torch.from_numpy(D))
+        out_i.copy_(torch.from_numpy(I))
+
+    link = ShardedFlatIndex(OracleLocal(), 0, device="cpu", merge=merge)
+
+    class StubModel:  # score = 1 / (1 + tokens in the pair): deterministic, batch-shape independent
+        class cfg:
+            type_vocab = 2
+
+        def classify(self, ids, types, sigmoid=True):
+            return np.array([[1.0 / (1 + len(s))] for s in ids], dtype=np.float32)
+
+    rr = Reranker(PipelineSettings(reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2"))
+    rr.model, rr.tokenizer, rr._max_len, rr._loaded = StubModel(), HashTokenizer(30522), 512, True
+
+    if rank == 0:
+        rng = np.random.default_rng(3)
+        words = ["alpha", "beta", "gamma", "delta", "epsilon", "zeta"]
+        queries = [" ".join(rng.choice(words, size=4)) for _ in range(5)]
+        docs = [[Document(doc_id=10 * qi + j, title="t", content=" ".join(rng.choice(words, size=int(rng.integers(3, 30)))))
+                 for j in range(int(rng.integers(0, 7)))] for qi in range(5)]
+        local = rr.rerank_batch(queries, docs, top_n=4)
+        rr.attach_shard_link(link)
+        Q = oracle.synth_rows(4321, 0, 6, d)
+        D0, I0 = link.leader_search(Q, 5)
+        shard = rr.rerank_batch(queries, docs, top_n=4)
+        D1, I1 = link.leader_search(Q[:2], 3)
+        same = all([(a.doc_id, a.score) for a in x] == [(b.doc_id, b.score) for b in y] for x, y in zip(local, shard))
+        np.savez(out_path, same=same, D0=D0, I0=I0, D1=D1, I1=I1)
+        link.shutdown()
+    else:
+        rr.attach_shard_link(link)
+        np.savez(out_path, served=link.follower_loop())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

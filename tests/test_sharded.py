@@ -67,6 +67,33 @@ def test_sharded_search_gloo_cpu_rehearsal(tmp_path, world, metric):
     _check(_launch("cpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
 
 
+def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
+    """Leader / follower protocol on CPU (world 3, gloo): searches and query-sharded rerank passes
+    interleave on the channel, the sharded rerank equals the one-process result exactly (stub model),
+    shutdown releases the followers."""
+    world, n, d = 3, 3001, 32
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"serve{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_serve_worker.py"), str(r), str(world), str(port), out],
+            env=dict(os.environ, OMP_NUM_THREADS="2")))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lead = np.load(outs[0])
+    assert bool(lead["same"])
+    X, Q = oracle.synth_rows(1234, 0, n, d), oracle.synth_rows(4321, 0, 6, d)
+    D0, I0 = oracle.search(X, Q, 5)
+    D1, I1 = oracle.search(X, Q[:2], 3)
+    np.testing.assert_array_equal(lead["I0"], I0)
+    np.testing.assert_array_equal(lead["D0"], D0)
+    np.testing.assert_array_equal(lead["I1"], I1)
+    np.testing.assert_array_equal(lead["D1"], D1)
+    assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])      # search, rerank, search
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,metric,k", [(2, 0, 10), (3, 0, 100), (2, 1, 10)])
 def test_sharded_search_real_kernels_two_ranks_one_gpu(gpu_required, tmp_path, world, metric, k):
