@@ -533,6 +533,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int XBK = 32, XLD = 40;
 // experiment-only switches (scripts/exp/gemm_x6_bench.hip; never defined in the product build)
+// RAGB_X6_TRACE=<workgroup>: that workgroup writes cycle stamps of its K loop (5 per iteration per wave)
+#if defined(RAGB_X6_TRACE)
+__device__ unsigned long long g_x6_trace[4 * 128 * 5];
+#define RAGB_X6_STAMP(i) do { if (blockIdx.x == RAGB_X6_TRACE && lane == 0 && kt < 128) g_x6_trace[(wave * 128 + kt) * 5 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RAGB_X6_STAMP(i) do {} while (0)
+#endif
 #if defined(RAGB_X6_NO_MFMA)
 #define RAGB_X6_MFMA(w, a, c) ([&] { asm volatile("" ::"v"(w), "v"(a)); return c; }())
 #else
@@ -567,7 +574,7 @@ struct GemmX6Params {
     int act;
 };
 
-__global__ __launch_bounds__(256) void gemm_nt_x6_kernel(const GemmX6Params p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_x6_kernel(const GemmX6Params p) {
     __shared__ __attribute__((aligned(16))) __bf16 As[2][3][128 * XLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
@@ -620,64 +627,102 @@ __global__ __launch_bounds__(256) void gemm_nt_x6_kernel(const GemmX6Params p) {
         }
     };
 
-    f32x4 ra[4];
+    // Software pipeline of one K-tile iteration (cycle stamps of the plain loop showed ~4000 cycles per
+    // iteration for 1536 cycles of MFMA even with the CU to itself: every phase waited for what it had
+    // issued a moment earlier).  Here everything an iteration consumes was requested an iteration before:
+    //   A rows      global -> registers one whole iteration ahead (two register sets, raA / raB)
+    //   A fragments LDS -> registers one K-step ahead (af0 / af1)
+    //   W fragments L2 -> registers one iteration ahead (refilled as soon as their MFMAs have issued)
+    // and an iteration is two branch-free scheduling regions (the last tiles stage / refill clamped,
+    // unused data) in which the hints spread loads, split arithmetic and LDS stores between the MFMAs:
+    //   step 0: MFMAs (kt, K-step 0) | A loads of tile kt + 2 | fragments of (kt, 1) | split + store tile kt + 1
+    //   barrier
+    //   step 1: MFMAs (kt, K-step 1) | fragments of (kt + 1, 0) | W refills
+    f32x4 raA[4], raB[4];
     bf16x8 wr[2][3][2];  // [K-step of the tile][plane][n tile]
+    auto load_a = [&](f32x4 (&ra)[4], int kt) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j]);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)kt * XBK);
+    };
+    auto read_af = [&](bf16x8 (&af)[3][2], int buf, int ks) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) wr[ks][pl][b] = wfrag[b][(size_t)(ks * 3 + pl) * 64];
-    stage(ra, 0, 0, 4);
-    if (nk > 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + XBK);
-    }
-    __syncthreads();
-
+            for (int a = 0; a < 2; ++a)
+                af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[buf][pl][(wm * 64 + a * 32 + r) * XLD + 16 * ks + 8 * h]);
+    };
     // (W plane, A plane) of the six kept terms, smallest first; the four output tiles take turns so that
     // dependent MFMAs on one accumulator are three instructions apart
     constexpr int kTerm[6][2] = {{0, 2}, {2, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;  // block-uniform
+    auto mfma24 = [&](const bf16x8 (&af)[3][2], int ks) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[3][2];
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    af[pl][a] = *reinterpret_cast<const bf16x8*>(&As[cur][pl][(wm * 64 + a * 32 + r) * XLD + 16 * ks + 8 * h]);
-            // the next tile's A rows are split and written into the other buffer under this step's MFMAs
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = RAGB_X6_MFMA(wr[ks][kTerm[t][0]][b], af[kTerm[t][1]][a], acc[a][b]);
+    };
+    auto refill_w = [&](int ks, int kt_next) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) wr[ks][pl][b] = wfrag[b][(size_t)((kt_next * 2 + ks) * 3 + pl) * 64];
+    };
+
+    load_a(raA, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) refill_w(ks, 0);
+    stage(raA, 0, 0, 4);
+    load_a(raB, min(1, nk - 1));   // tile 1: staged during iteration 0
+    __syncthreads();
+    bf16x8 af0[3][2], af1[3][2];
+    read_af(af0, 0, 0);
+
+    auto iteration = [&](int kt, int cur, const f32x4 (&ra_stage)[4], f32x4 (&ra_load)[4]) {
+        const int kt1 = min(kt + 1, nk - 1), kt2 = min(kt + 2, nk - 1);
+        // ---- step 0
+        RAGB_X6_STAMP(0);
+        load_a(ra_load, kt2);
+        read_af(af1, cur, 1);
 #ifndef RAGB_X6_NO_STAGE
-            if (more) stage(ra, cur ^ 1, 2 * ks, 2 * ks + 2);
+        stage(ra_stage, cur ^ 1, 0, 4);
 #endif
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = RAGB_X6_MFMA(wr[ks][kTerm[t][0]][b], af[kTerm[t][1]][a], acc[a][b]);
+        mfma24(af0, 0);
 #ifndef RAGB_X6_NO_WLOAD
-            if (more) {  // this step's W registers are free once its MFMAs have issued: refill for the next tile
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        wr[ks][pl][b] = wfrag[b][(size_t)(((kt + 1) * 2 + ks) * 3 + pl) * 64];
-            }
+        refill_w(0, kt1);
 #endif
-        }
-        if (kt + 2 < nk) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);    // A loads of tile kt + 2
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // A fragments of this tile's second step
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)(kt + 2) * XBK);
+        for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);  // a share of the split arithmetic
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // one LDS store
         }
+        __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);    // W refills of step 0
+        RAGB_X6_STAMP(1);
         __syncthreads();
+        RAGB_X6_STAMP(2);
+        // ---- step 1
+        read_af(af0, cur ^ 1, 0);
+        mfma24(af1, 1);
+#ifndef RAGB_X6_NO_WLOAD
+        refill_w(1, kt1);
+#endif
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);    // A fragments of the next tile's first step
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (g >= 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // W refills under the second half
+        }
+        RAGB_X6_STAMP(3);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        iteration(kt, 0, raB, raA);          // stages tile kt + 1 (in raB), loads tile kt + 2 into raA
+        if (kt + 1 < nk) iteration(kt + 1, 1, raA, raB);
     }
+    __syncthreads();  // every wave is done with the A image
 #ifdef RAGB_X6_NO_STORE
     {
         float live = 0.f;

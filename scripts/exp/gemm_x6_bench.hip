@@ -30,7 +30,24 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         if (rep) printf("%-22s M=%6d N=%5d K=%5d: %7.3f ms %6.1f TF/s (fp32-equivalent)\n", name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
     }
-    hipFree(A); hipFree(W); hipFree(C); hipFree(R); hipFree(b); hipFree(Wx);
+#if defined(RAGB_X6_TRACE)
+    {
+        static unsigned long long h[4 * 128 * 5];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(ragb::g_x6_trace), sizeof h));
+        const int nk = K / 32 < 128 ? K / 32 : 128;
+        printf("  trace of workgroup %d (cycles; per wave and K-tile: step 0, barrier wait, step 1 | whole iteration)\n", RAGB_X6_TRACE);
+        for (int w = 0; w < 4; ++w) {
+            printf("  wave %d:", w);
+            for (int kt = 0; kt < nk && kt < 12; ++kt) {
+                const unsigned long long* t = h + (w * 128 + kt) * 5;
+                const unsigned long long next0 = kt + 1 < nk ? h[(w * 128 + kt + 1) * 5] : t[3];
+                printf(" [%llu %llu %llu | %llu]", t[1] - t[0], t[2] - t[1], t[3] - t[2], next0 - t[0]);
+            }
+            printf("\n");
+        }
+    }
+#endif
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(C); (void)hipFree(R); (void)hipFree(b); (void)hipFree(Wx);
 }
 
 int main() {
