@@ -341,6 +341,31 @@ def test_lz4_frame_round_trips_and_header_checksum():
     assert len(lz4frame.compress(text)) < len(text) // 2    # it does compress
 
 
+def test_lz4_frame_fuzz_round_trip():
+    """300 seeded buffers mixing literals, short and long matches, overlapping copies and block
+    boundaries of the token format (lengths around 15 / 270, offsets up to 65535)."""
+    from rag_inference_pipeline_amd import lz4frame
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        parts = []
+        for _ in range(int(rng.integers(1, 12))):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                parts.append(rng.integers(0, 256, size=int(rng.integers(0, 400)), dtype=np.uint8).tobytes())
+            elif kind == 1:
+                parts.append(bytes([int(rng.integers(0, 256))]) * int(rng.choice([1, 4, 14, 15, 16, 19, 269, 270, 271, 5000])))
+            elif kind == 2:
+                unit = rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+                parts.append(unit * int(rng.integers(1, 60)))
+            elif parts:
+                parts.append(parts[int(rng.integers(0, len(parts)))])          # a far back-reference
+        data = b"".join(parts)
+        assert lz4frame.decompress(lz4frame.compress(data)) == data, trial
+    far = np.random.default_rng(8).integers(0, 256, size=300, dtype=np.uint8).tobytes()
+    data = far + bytes(70_000) + far                       # the second copy is beyond the 64 KiB window
+    assert lz4frame.decompress(lz4frame.compress(data)) == data
+
+
 def test_executor_result_cache_hits_skip_the_index():
     index = _Index()
     ex, _ = _executor({"faiss_store": index}, DISABLE_CACHE_FOR_PROFILING="false")
