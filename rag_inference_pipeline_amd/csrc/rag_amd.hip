@@ -89,6 +89,11 @@ ScanFn screen_fn(int cap, int ring, bool l2) {
         default: return screen_fn_cap<4>(ring, l2);
     }
 }
+#ifdef RAGK_TUNING
+ScanFn screen_fn12(bool l2) {  // experiment: 12 waves, cap 64, ring 8
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<12, 1, 8, true, 1> : (ScanFn)ragk::scan_topk_kernel<12, 1, 8, false, 1>;
+}
+#endif
 template <int NW, int E>
 ScanFn scan_fn_ring(int ring, bool l2) {
     switch (ring) {
@@ -516,7 +521,10 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     const int kp = 240;
     const int cap = screen_capacity(h->d64, k);
     const bool l2 = h->metric == RAG_METRIC_L2;
-    const int waves = 8;
+    int waves = 8;
+#ifdef RAGK_TUNING
+    if (env_int("RAG_AMD_SCREEN_WAVES", 0) == 12 && cap == 64 && (h->d64 / 16) % 8 == 0) waves = 12;
+#endif
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
     const int n_tiles = (int)n_tiles_ll;
     int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + waves - 1) / waves);
@@ -583,6 +591,9 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         sp.thr_key = h->thr_keys;  // allocated by the first sample pass
     }
     ScanFn fn = screen_fn(cap, S % 8 == 0 ? 8 : 4, l2);
+#ifdef RAGK_TUNING
+    if (waves == 12) fn = screen_fn12(l2);
+#endif
     const size_t lds = scan_lds_bytes(h->d64 / 2, cap);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0 = nullptr, e1 = nullptr;
