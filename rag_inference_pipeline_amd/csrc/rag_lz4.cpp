@@ -30,7 +30,7 @@ uint8_t* put_sequence(uint8_t* op, const uint8_t* op_end, const uint8_t* lit, in
     } else {
         *token = (uint8_t)(l << 4);
     }
-    std::memcpy(op, lit, (size_t)nlit);
+    if (nlit > 0) std::memcpy(op, lit, (size_t)nlit);
     op += nlit;
     if (mlen > 0) {
         *op++ = (uint8_t)(offset & 0xFF);
@@ -52,7 +52,7 @@ uint8_t* put_sequence(uint8_t* op, const uint8_t* op_end, const uint8_t* lit, in
 extern "C" int64_t rag_lz4_compress_bound(int64_t n) { return n < 0 ? 0 : n + n / 255 + 16; }
 
 extern "C" int64_t rag_lz4_block_compress(const uint8_t* src, int64_t n, uint8_t* dst, int64_t cap) {
-    if (!src || !dst || n < 0 || cap < 0) return -1;
+    if ((!src && n > 0) || !dst || n < 0 || cap < 0) return -1;
     uint8_t* op = dst;
     const uint8_t* const op_end = dst + cap;
     int64_t anchor = 0;

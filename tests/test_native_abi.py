@@ -132,3 +132,26 @@ def test_product_package_never_touches_the_oracle_or_the_reference():
         if "/root/reference" in path.read_text():
             offenders.append(str(path))
     assert not offenders, offenders
+
+
+def test_lz4_block_compressor_under_address_and_ub_sanitizers(tmp_path):
+    """The host-side C++ of the ABI, built for the CPU with -fsanitize=address,undefined and fuzzed
+    (tests/native/lz4_fuzz.cpp: 20 000 buffers, exact-size destinations, too-small destinations refused).
+    GPU sanitizers are not available; this is the part of the library a CPU sanitizer can see."""
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "lz4_fuzz")
+    build = subprocess.run([gxx, "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
+                            "-I", os.path.join(root, "include"), os.path.join(root, "tests", "native", "lz4_fuzz.cpp"),
+                            os.path.join(root, "rag_inference_pipeline_amd", "csrc", "rag_lz4.cpp"), "-o", exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr.lower() + build.stdout.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "fuzz ok" in run.stdout and "runtime error" not in run.stderr, run.stdout + run.stderr
