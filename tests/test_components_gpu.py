@@ -1,6 +1,8 @@
 """GPU: the drop-in components behind the reference's plugin surface."""
 import asyncio
 
+import os
+
 import numpy as np
 import pytest
 
@@ -243,3 +245,18 @@ def test_build_index_tool_embeds_documents_and_round_trips(gpu_required, tmp_pat
     D, I = store.search(gen.encode([texts[i] for i in probe]), 3)
     assert I[:, 0].tolist() == probe and np.allclose(D[:, 0], 1.0, atol=1e-5)
     store.unload(); gen.unload()
+    # the same build as three processes sharing the GPU (one per "rank"): the same file
+    import subprocess
+    import sys
+    out3 = tmp_path / "faiss_index_3ranks.f32"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-m", "rag_inference_pipeline_amd.tools.build_index", "--documents-dir",
+                               str(docs_dir), "--model", model, "--out", str(out3), "--batch-docs", "64",
+                               "--rank", str(r), "--world", "3", "--device", "0"], cwd=root) for r in range(3)]
+    assert all(p.wait(timeout=300) == 0 for p in procs)
+    a3, a1 = np.fromfile(out3, dtype=np.float32), np.fromfile(out, dtype=np.float32)
+    assert a3.shape == a1.shape and np.abs(a3 - a1).max() < 2e-6   # other batch shapes, other GEMM paths: fp32 rounding
+    import json
+    side = json.loads((tmp_path / "faiss_index_3ranks.f32.json").read_text())
+    assert side["ntotal"] == 300 and side["d"] == 384 and side["ranks"] == 3
+    assert not list(tmp_path.glob("*.done"))
