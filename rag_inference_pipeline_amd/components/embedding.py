@@ -24,7 +24,7 @@ import numpy as np
 
 from ..bert import iter_token_budget
 from ..cache import LRUCache
-from ..config import PipelineSettings
+from ..config import PipelineSettings, resolve_gpu_device
 
 logger = logging.getLogger(__name__)
 
@@ -35,7 +35,8 @@ class EmbeddingGenerator:
     def __init__(self, settings: PipelineSettings) -> None:
         self.settings = settings
         self.model_name = settings.embedding_model_name
-        self.device = f"cuda:{int(getattr(settings, 'gpu_device', 0))}"
+        self._device_index = resolve_gpu_device(settings)
+        self.device = f"cuda:{self._device_index}"
         self._model = None
         self._tokenizer = None
         self._max_len = 512
@@ -54,7 +55,9 @@ class EmbeddingGenerator:
             from ..model_source import resolve_model
 
             cfg, weights, tokenizer, max_len = resolve_model(self.model_name, "embedding")
-            self._model = BertModel(cfg, weights, device=int(getattr(self.settings, "gpu_device", 0)))
+            self._device_index = resolve_gpu_device(self.settings)  # the group may have been set up since
+            self.device = f"cuda:{self._device_index}"
+            self._model = BertModel(cfg, weights, device=self._device_index)
             self._tokenizer, self._max_len = tokenizer, max_len
             self._is_loaded = True
             # warm-up on a longer text, as the reference does (:84-93)

@@ -27,7 +27,7 @@ from pathlib import Path
 import numpy as np
 
 from .. import _native, index_io
-from ..config import PipelineSettings
+from ..config import PipelineSettings, resolve_gpu_device
 
 logger = logging.getLogger(__name__)
 
@@ -61,16 +61,13 @@ class FAISSStore:
             rows, metric = index_io.read_index_file(
                 self.index_path, default_metric, mmap=bool(getattr(self.settings, "faiss_use_mmap", False)))
             n, d = rows.shape
-            device = int(getattr(self.settings, "gpu_device", 0))
+            device = resolve_gpu_device(self.settings)  # LOCAL_RANK / current device when one process per GPU
             rank, world = self._dist_rank_world()
             row_lo, row_hi = 0, n
             if world > 1:
                 from ..sharded import shard_range
 
                 row_lo, row_hi = shard_range(n, rank, world)
-                import torch
-
-                device = torch.cuda.current_device()  # the launcher binds one GPU per rank
             index = FlatIndex(d, metric, device=device)
             index.reserve(row_hi - row_lo)
             for lo in range(row_lo, row_hi, _ADD_CHUNK_ROWS):

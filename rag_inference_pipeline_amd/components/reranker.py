@@ -26,7 +26,7 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 from ..bert import iter_token_budget
-from ..config import PipelineSettings
+from ..config import PipelineSettings, resolve_gpu_device
 from .schemas import Document, RerankedDocument
 
 logger = logging.getLogger(__name__)
@@ -43,7 +43,8 @@ class Reranker:
     def __init__(self, settings: PipelineSettings) -> None:
         self.settings = settings
         self.model_name = settings.reranker_model_name
-        self.device = f"cuda:{int(getattr(settings, 'gpu_device', 0))}"
+        self._device_index = resolve_gpu_device(settings)
+        self.device = f"cuda:{self._device_index}"
         self.tokenizer = None
         self.model = None
         self._max_len = 512
@@ -64,7 +65,9 @@ class Reranker:
 
             cfg, weights, tokenizer, max_len = resolve_model(self.model_name, "reranker")
             cfg.gemm_dtype = str(getattr(self.settings, "reranker_dtype", "f32")).lower().replace("fp", "f")
-            self.model = BertModel(cfg, weights, device=int(getattr(self.settings, "gpu_device", 0)))
+            self._device_index = resolve_gpu_device(self.settings)  # the group may have been set up since
+            self.device = f"cuda:{self._device_index}"
+            self.model = BertModel(cfg, weights, device=self._device_index)
             self.tokenizer, self._max_len = tokenizer, max_len
             self._loaded = True
             self._score_pairs(["query " * 10], ["document " * 100])  # warm-up (:156-166)
@@ -149,6 +152,10 @@ class Reranker:
         their side of the exchange and serve it from the store's follower loop."""
         from ..sharded import OP_RERANK
 
+        if link is not None and self._loaded and getattr(link.device, "type", "cpu") == "cuda" \
+                and int(link.device.index or 0) != self._device_index:
+            raise RuntimeError(f"reranker is on cuda:{self._device_index} but this rank's index shard is on "
+                               f"{link.device}: both follow config.resolve_gpu_device()")
         self._link = link
         if link is not None and link.rank != 0:
             link.register_handler(OP_RERANK, self._follower_pass)
@@ -176,11 +183,12 @@ class Reranker:
         dist, group, world = link._dist, link.group, link.world
         parts = [[(qi, queries[qi], [d.content for d in documents_batch[qi]]) for qi in range(r, len(queries), world)]
                  for r in range(world)]
-        link.leader_call(OP_RERANK)
-        recv: list = [None]
-        dist.scatter_object_list(recv, parts, src=0, group=group)
         gathered: list = [None] * world
-        dist.gather_object(self._score_work(recv[0]), gathered, dst=0, group=group)
+        with link.exclusive():  # head + scatter + gather are one request: batches run on several threads
+            link.leader_call(OP_RERANK)
+            recv: list = [None]
+            dist.scatter_object_list(recv, parts, src=0, group=group)
+            dist.gather_object(self._score_work(recv[0]), gathered, dst=0, group=group)
         scores: list[list[float]] = [[] for _ in queries]
         for part in gathered:
             for qi, sc in part:

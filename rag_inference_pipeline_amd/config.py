@@ -85,6 +85,30 @@ class PipelineSettings(BaseModel):
         return cls(**values)
 
 
+def resolve_gpu_device(settings: Any = None) -> int:
+    """The GPU this process's components live on — one rule for index, encoder and cross-encoder.
+
+    One process, one GPU (the reference's deployment, and any group of one rank): `settings.gpu_device`
+    (RAG_AMD_DEVICE, default 0).  One process per GPU under an initialised torch.distributed group of
+    more than one rank: the launcher's binding — LOCAL_RANK when the launcher exports it (torchrun
+    does), else torch's current device.  Without this rule every rank's cross-encoder would sit on GPU 0
+    beside shard 0 while only the index followed the rank."""
+    base = int(getattr(settings, "gpu_device", 0) or 0)
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return base
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return base
+    import torch
+
+    n = torch.cuda.device_count()
+    local = os.environ.get("LOCAL_RANK")
+    if local is not None and n > 0:
+        return int(local) % n
+    return torch.cuda.current_device() if n > 0 else base
+
+
 _settings: PipelineSettings | None = None
 
 

@@ -17,6 +17,7 @@ memory, which is how the multi-rank path is exercised on CPU-only and single-GPU
 
 from __future__ import annotations
 
+import threading
 from typing import Any, Callable, Protocol
 
 import numpy as np
@@ -72,6 +73,13 @@ class ShardedFlatIndex:
             self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self._merge = merge
         self._bufs: dict[tuple[int, int], dict[str, Any]] = {}
+        # One request at a time on the serving channel.  The reference's scheduler starts every flushed
+        # batch as its own task on a pool thread (gateway/batch_scheduler.py:286-288), so rank 0 can be
+        # inside search()/rerank_batch() on several threads at once; a request is a SEQUENCE of
+        # collectives (head, payload, gather, merge, read-back of the per-shape buffers) that the
+        # followers replay in order, so two of them must never interleave.  Re-entrant: leader_search
+        # holds it around search().
+        self._lock = threading.RLock()
 
     # -- buffers ---------------------------------------------------------------------------------
     def _buffers(self, nq: int, k: int) -> dict[str, Any]:
@@ -132,11 +140,12 @@ class ShardedFlatIndex:
     def search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
         """Host convenience (collective): numpy in, numpy out, same contract as FlatIndex.search."""
         torch = self._torch
-        q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self.device)
-        s, i = self.search_tensors(q, k)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
-        return s.cpu().numpy().copy(), i.cpu().numpy().copy()
+        with self._lock:  # the per-shape buffers are shared: keep them until the result is on the host
+            q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self.device)
+            s, i = self.search_tensors(q, k)
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            return s.cpu().numpy().copy(), i.cpu().numpy().copy()
 
     # -- serving: rank 0 answers requests, the other ranks follow -------------------------------------
     # The reference's retrieval node is ONE process (uvicorn) calling index.search(); with the corpus
@@ -157,9 +166,16 @@ class ShardedFlatIndex:
             raise ValueError(f"op {op} is reserved")
         self._handlers[int(op)] = fn
 
+    def exclusive(self) -> Any:
+        """`with link.exclusive():` — hold the serving channel for one whole request: the head, every
+        collective that follows it and the read-back of the result.  leader_search() takes it itself;
+        a component that drives its own exchange through leader_call() (the reranker) wraps the
+        exchange in it."""
+        return self._lock
+
     def leader_call(self, op: int) -> None:
         """Rank 0: put every follower into its handler for `op`; the caller then runs the same
-        collectives the handler runs."""
+        collectives the handler runs — inside `with link.exclusive():`."""
         if self.rank != 0:
             raise RuntimeError("leader_call() is for rank 0")
         if self.world > 1:
@@ -171,10 +187,11 @@ class ShardedFlatIndex:
             raise RuntimeError("leader_search() is for rank 0; other ranks run follower_loop()")
         torch, dist = self._torch, self._dist
         q = np.ascontiguousarray(queries, dtype=np.float32)
-        self._send_head(OP_SEARCH, q.shape[0], int(k), q.shape[1])
-        qt = torch.from_numpy(q).to(self._ctl_device())
-        dist.broadcast(qt, src=0, group=self.group)
-        return self.search(q, k)
+        with self._lock:
+            self._send_head(OP_SEARCH, q.shape[0], int(k), q.shape[1])
+            qt = torch.from_numpy(q).to(self._ctl_device())
+            dist.broadcast(qt, src=0, group=self.group)
+            return self.search(q, k)
 
     def follower_loop(self) -> int:
         """Ranks > 0: serve the leader's requests until it sends shutdown(); returns the number served."""
@@ -201,4 +218,5 @@ class ShardedFlatIndex:
     def shutdown(self) -> None:
         """Rank 0: release the followers from follower_loop()."""
         if self.rank == 0 and self.world > 1:
-            self._send_head(OP_SHUTDOWN)
+            with self._lock:
+                self._send_head(OP_SHUTDOWN)

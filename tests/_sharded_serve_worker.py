@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main() -> None:
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     n, d = 3001, 32
     import torch
     import torch.distributed as dist
@@ -62,6 +63,40 @@ def main() -> None:
         local = rr.rerank_batch(queries, docs, top_n=4)
         rr.attach_shard_link(link)
         Q = oracle.synth_rows(4321, 0, 6, d)
+        if threads:
+            # the scheduler's situation (reference batch_scheduler.py:286-288): several batches in flight on
+            # pool threads of rank 0, searches of equal and different shapes and rerank passes all at once
+            import threading
+
+            X = oracle.synth_rows(1234, 0, n, d)
+            want_rr = [[(b.doc_id, b.score) for b in y] for y in local]
+            errors, rounds = [], 6
+
+            def client(t: int) -> None:
+                try:
+                    for it in range(rounds):
+                        nq, k = ((6, 5), (2, 3), (6, 5), (4, 7))[(t + it) % 4]
+                        Qt = oracle.synth_rows(9000 + 17 * t + it, 0, nq, d)
+                        D, I = link.leader_search(Qt, k)
+                        Dw, Iw = oracle.search(X, Qt, k)
+                        if not (np.array_equal(I, Iw) and np.array_equal(D, Dw)):
+                            errors.append(f"thread {t} round {it}: search differs")
+                        got = rr.rerank_batch(queries, docs, top_n=4)
+                        if [[(a.doc_id, a.score) for a in x] for x in got] != want_rr:
+                            errors.append(f"thread {t} round {it}: rerank differs")
+                except Exception as exc:  # a mismatched collective surfaces here (or as a hang -> test timeout)
+                    errors.append(f"thread {t}: {type(exc).__name__}: {exc}")
+
+            pool = [threading.Thread(target=client, args=(t,)) for t in range(threads)]
+            for th in pool:
+                th.start()
+            for th in pool:
+                th.join()
+            np.savez(out_path, errors=np.array(errors, dtype=str), requests=2 * rounds * threads)
+            link.shutdown()
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         D0, I0 = link.leader_search(Q, 5)
         shard = rr.rerank_batch(queries, docs, top_n=4)
         D1, I1 = link.leader_search(Q[:2], 3)

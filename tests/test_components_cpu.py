@@ -106,3 +106,28 @@ def test_lru_cache_ttl_and_eviction():
     c.put("x", np.ones(2))
     import time; time.sleep(0.01)
     assert c.get("x") is None
+
+
+def test_one_device_rule_for_every_component(monkeypatch):
+    """index, encoder and cross-encoder must agree on the GPU.  Alone: RAG_AMD_DEVICE.  One
+    process per GPU (initialised group, world > 1): LOCAL_RANK, else torch's current device."""
+    import torch
+    import torch.distributed as dist
+
+    from rag_inference_pipeline_amd.config import PipelineSettings, resolve_gpu_device
+    from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+    from rag_inference_pipeline_amd.components.reranker import Reranker
+
+    s = PipelineSettings(RAG_AMD_DEVICE=3)
+    assert resolve_gpu_device(s) == 3 and resolve_gpu_device(None) == 0
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 8)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 5)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert resolve_gpu_device(s) == 5
+    monkeypatch.setenv("LOCAL_RANK", "6")
+    assert resolve_gpu_device(s) == 6
+    assert EmbeddingGenerator(s).device == "cuda:6" and Reranker(s).device == "cuda:6"
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1)   # a group of one is the plain deployment
+    assert resolve_gpu_device(s) == 3

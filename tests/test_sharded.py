@@ -94,6 +94,32 @@ def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
     assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])      # search, rerank, search
 
 
+def test_concurrent_batches_on_the_serving_channel(tmp_path):
+    """The scheduler runs batches concurrently on pool threads (reference batch_scheduler.py:286-288,
+    retrieval/api.py:348-349): four threads on rank 0 issue searches (same and different shapes) and
+    query-sharded rerank passes at once.  Each request's collectives must stay together — every answer
+    equals the oracle's, nothing hangs, and the followers serve exactly the number of requests issued."""
+    world, threads = 3, 4
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"conc{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_serve_worker.py"), str(r), str(world), str(port), out,
+             str(threads)], env=dict(os.environ, OMP_NUM_THREADS="2")))
+    try:
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lead = np.load(outs[0])
+    assert lead["errors"].size == 0, lead["errors"].tolist()
+    assert all(int(np.load(o)["served"]) == int(lead["requests"]) for o in outs[1:])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,metric,k", [(2, 0, 10), (3, 0, 100), (2, 1, 10)])
 def test_sharded_search_real_kernels_two_ranks_one_gpu(gpu_required, tmp_path, world, metric, k):
