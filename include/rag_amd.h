@@ -97,7 +97,9 @@ int64_t rag_index_ntotal(const rag_index* h);
 int32_t rag_index_dim(const rag_index* h);
 int32_t rag_index_metric(const rag_index* h);
 
-/* Value added to every returned id (shard base row when the corpus is split over GPUs). */
+/* Value added to every returned id (shard base row when the corpus is split over GPUs).
+ * Global ids must fit 32 bits (the shard merge ranks 64-bit keys that carry the id in their low word):
+ * 0 <= id_offset and id_offset + ntotal <= 2^32 - 1, else RAG_ERR_UNSUPPORTED — also from a later add. */
 int rag_index_set_id_offset(rag_index* h, int64_t id_offset);
 
 /* Exact search.  Replaces index.search(embeddings, k) (faiss_store.py:152).
@@ -106,7 +108,18 @@ int rag_index_set_id_offset(rag_index* h, int64_t id_offset);
  *                  distances sorted ascending (L2)
  *   out_ids      : nq x k int64 — row ids; slots beyond ntotal hold -1 with score
  *                  -FLT_MAX (IP) / +FLT_MAX (L2), as IndexFlat pads them
- * Ties are broken by ascending id.  Blocks until the results are in the output buffers. */
+ * Ties are broken by ascending id.  Blocks until the results are in the output buffers.
+ *
+ * Non-finite values.  Selection follows the heap faiss runs behind IndexFlat.search: it starts at
+ * -FLT_MAX (IP) / +FLT_MAX (L2) and admits a candidate only if it compares strictly better.  Hence:
+ *   - a row whose ranking score (IP: q.x; L2: 2 q.x - ||x||^2) is NaN, -inf or -FLT_MAX is never
+ *     returned; if fewer than k rows remain, the tail is (-1, -FLT_MAX / +FLT_MAX) padding;
+ *   - a query containing NaN therefore gets k padding slots; +inf scores rank first, ties by id;
+ *   - L2: a query whose squared norm is inf or NaN gets k padding slots (every distance is inf or NaN);
+ *   - products follow IEEE-754 (inf * 0 = NaN, inf - inf = NaN) in the canonical summation order;
+ *   - the two-stage search (rag_index_set_screening) stands aside: a corpus with non-finite or
+ *     extreme values reports RAG_SCREEN_INACTIVE, an out-of-range query is answered by the fp32 scan.
+ * Held to oracle/flat_oracle.c by tests/test_flat_gpu.py::test_nonfinite_*. */
 int rag_index_search(rag_index* h, const float* queries_host, int32_t nq, int32_t k,
                      float* out_scores, int64_t* out_ids);
 

@@ -21,6 +21,8 @@
  *     BLAS and on nq, so it is not reproducible across batch sizes either);
  *   - ties: equal score -> smaller id first;
  *   - L2: dist = ||q||^2 - (2*ip - ||x||^2), clamped at 0 (FAISS's BLAS path clamps too).
+ * Non-finite values follow the heap FAISS selects with: a row whose ranking score is NaN, -inf or
+ * -FLT_MAX is never returned (rago_search below); +inf scores rank first like any other value.
  *
  * Build: make -C oracle   (gcc -O3 -mavx2 -mfma -fopenmp, -ffp-contract=off)
  */
@@ -220,8 +222,18 @@ int rago_search(const float* X, int64_t N, int32_t d, int32_t metric, const floa
                 const float* x = X + (size_t)r * d;
                 row_scores(x, d, d8, Qt, sc);
                 float xn = metric == RAGO_METRIC_L2 ? rago_sqnorm(x, d) : 0.0f;
-                for (int32_t b = 0; b < nb; ++b)
-                    topk_push(&tk[b], make_key(rank_score(sc[b], xn, metric), (uint32_t)r));
+                for (int32_t b = 0; b < nb; ++b) {
+                    /* L2: faiss admits dist < FLT_MAX only; with ||q||^2 non-finite every distance
+                     * is inf or NaN, so such a query has no results at all. */
+                    if (metric == RAGO_METRIC_L2 && !(qn[b] <= FLT_MAX)) continue;
+                    float rs = rank_score(sc[b], xn, metric);
+                    /* The heap behind IndexFlat.search starts at -FLT_MAX (IP; +FLT_MAX for L2) and
+                     * admits a candidate only if it compares strictly better (faiss heap / result
+                     * handler semantics): a score that is NaN, -inf or -FLT_MAX never becomes a
+                     * result and its slot stays (-1, -FLT_MAX).  Same rule here and in the HIP path. */
+                    if (!(rs > -FLT_MAX)) continue;
+                    topk_push(&tk[b], make_key(rs, (uint32_t)r));
+                }
             }
             for (int b = 0; b < RAGO_QT; ++b) counts[(size_t)tid * RAGO_QT + b] = tk[b].n;
         }

@@ -63,7 +63,7 @@ struct EmbedParams {
     const float* ln_g;
     const float* ln_b;
     float* out;            // [T][H]
-    int T, nseq, H, pos_offset, max_pos, vocab;
+    int T, nseq, H, pos_offset, max_pos, vocab, type_vocab;
     float eps;
 };
 
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const EmbedParams p) {
     pos = pos < p.max_pos ? pos : p.max_pos - 1;
     int id = p.ids[t];
     id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
-    const int ty = p.type_ids ? p.type_ids[t] : 0;
+    int ty = p.type_ids ? p.type_ids[t] : 0;  // clamped like id and pos: a pair-encoded input on a one-type checkpoint
+    ty = ty < 0 ? 0 : (ty >= p.type_vocab ? p.type_vocab - 1 : ty);  // must not read past the table
     const float* w = p.word_emb + (size_t)id * p.H;
     const float* pe = p.pos_emb + (size_t)pos * p.H;
     const float* te = p.type_emb ? p.type_emb + (size_t)ty * p.H : nullptr;

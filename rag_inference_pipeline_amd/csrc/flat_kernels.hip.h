@@ -37,6 +37,13 @@ constexpr int kQT = 32;        // queries per scan pass (MFMA N)
 constexpr int kTileRows = 32;  // corpus rows per wave tile (MFMA M)
 constexpr int kMaxScanWaves = 16;
 
+// Lowest ranking score a result may have: the filters test `score >= kScoreFloor`, i.e. score > -FLT_MAX.
+// That is the contract of the heap behind faiss IndexFlat.search (the reference's call, faiss_store.py:152):
+// its top-k heap starts at -FLT_MAX (IP; +FLT_MAX for L2) and a candidate enters only if it compares
+// strictly better, so rows whose score is NaN, -inf or -FLT_MAX are never returned and their slots stay
+// (-1, -FLT_MAX).  include/rag_amd.h states the same contract; oracle/flat_oracle.c follows it.
+#define RAGK_SCORE_FLOOR __uint_as_float(0xFF7FFFFEu) /* nextafter(-FLT_MAX, 0) */
+
 // ---- ranking keys -------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t ord32(float f) {
@@ -126,6 +133,7 @@ __device__ __forceinline__ f32x16 scan_step(const f32x4 x, const f32x4 q, f32x16
 struct ScanParams {
     const float* X;        // corpus, row-major, row_stride floats per row (zero padded to d8)
     const float* xnorm;    // canonical squared norms (L2 metric only)
+    const float* qnorm;    // canonical ||q||^2 per query (L2 metric only): a non-finite one means no results
     const float* Q;        // queries, row-major nq x d (un-padded)
     u64* partial;          // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
     const u64* ceil;       // [kQT] or null: only keys strictly below ceil[q] are candidates (k > max_k rounds)
@@ -141,7 +149,8 @@ struct ScanParams {
     int nq;                // 1..32
     int k;
     int n_tiles;           // ceil(n_rows / 32)
-    int n_iters;           // tiles per wave
+    int n_iters;           // rounds of the tile walk (the last one may be partial)
+    int n_full;            // rounds in which every wave of every workgroup has a tile: n_tiles / (grid * NW)
     const uint32_t* enable;  // null, or a device word: 0 turns the whole launch into a no-op (fallback path)
     const u64* thr_key;      // null, or [kQT] keys (0 = none) whose score >= k rows are known to reach (sample pass):
                              // the filter starts there instead of at -inf
@@ -186,52 +195,134 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
     float* mrg = reinterpret_cast<float*>(flag + 4);
 
-    if (P == 1) {
-        // ---- prologue: queries -> fp16 B fragments.  Fragment (s, l) = Q[l&31][16s + 8(l>>5) .. +7] * qscale.
-        for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
-            const int s = idx >> 6, l = idx & 63;
-            const int qrow = l & 31, col = 16 * s + 8 * (l >> 5);
-            f16x8 v;
+    // ---- tile walk.  Rounds 0 .. n_full-1: wave w of workgroup b takes tile (b NW + w) + round * grid * NW
+    // (the 8 waves of a workgroup read 8 consecutive tiles).  The last, partial round hands its leftover
+    // tiles out ONE PER WORKGROUP first (tile = base + w * grid + b): a leftover tile done by a lone wave
+    // on an otherwise idle CU costs a third of a full round, and every CU gets one before any gets two.
+    // (With whole 8-tile groups in the last round, 1.25M rows = 19.07 rounds ran as 20: 19 CUs streamed
+    // a 20th group while 237 idled — 5 % of the scan.)
+    const long long last_row = p.n_rows - 1;
+    const long long tile_rows = (long long)kTileRows * p.tile_step;  // distance between consecutive tiles' first rows
+    const int tiles_per_iter = gridDim.x * kScanWaves;
+    auto tile_of = [&](int it) -> int {
+        return it < p.n_full ? (int)blockIdx.x * kScanWaves + wave + it * tiles_per_iter
+                             : p.n_full * tiles_per_iter + wave * (int)gridDim.x + (int)blockIdx.x;
+    };
+    auto row_ptr = [&](int t) -> const float* {
+#if defined(RAGK_ABLATE_L2_WINDOW)
+        t &= 31;
+#endif
+        long long row = (long long)t * tile_rows + r;
+        row = row < last_row ? row : last_row;
+        return p.X + row * p.row_stride + p.col0 + 4 * h;
+    };
+    // the first ring loads go out before the query image is built: their HBM latency runs under the prologue
+    int tile = tile_of(0);
+    f32x4 xb[D];
+    const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
-            if (qrow < p.nq) {
-                const float* src = p.Q + (size_t)qrow * p.d + col;
-                const float qs = p.qscale[qrow];
+    for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+
+    // ---- prologue: queries -> MFMA B fragments in LDS.  A thread's lane (hence its query row and column
+    // half) is the same in every trip, so its loads differ only in the step s: PU of them are issued back to
+    // back before the first LDS store (one trip at a time the twelve dependent L2 round trips of d = 768 were
+    // most of the kernel's fixed cost — every CU reads the same 96 KB at the same moment), and each
+    // workgroup starts at a different step so the 256 CUs do not all ask for the same lines at once.
+    {
+        constexpr int PU = 6;
+        constexpr int WPS = kScanWaves;             // steps covered per trip: one per wave
+        const int qrow = lane & 31, hh = lane >> 5;
+        const int rot = (int)((blockIdx.x * 5u) % (unsigned)S);
+        if (P == 1) {
+            // fragment (s, l) = Q[l&31][16s + 8(l>>5) .. +7] * qscale, as fp16
+            const float qsc = qrow < p.nq ? p.qscale[qrow] : 0.f;
+            const float* qbase = p.Q + (size_t)(qrow < p.nq ? qrow : 0) * p.d;
+            const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
+            for (int s0 = wave; s0 < S; s0 += WPS * PU) {
+                f32x4 va[PU], vb[PU];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (col + j < p.d) v[j] = (_Float16)(src[j] * qs);
-            }
-            qf[idx] = __builtin_bit_cast(f32x4, v);
-        }
-    } else {
-        // ---- prologue: queries -> MFMA B fragments.  Fragment (s, l) = Q[l&31][8s + 4(l>>5) .. +3].
-        const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
-        for (int idx = tid; idx < S * 64; idx += kScanWaves * 64) {
-            const int s = idx >> 6, l = idx & 63;
-            const int qrow = l & 31, col = p.col0 + 8 * s + 4 * (l >> 5);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (qrow < p.nq) {
-                const float* src = p.Q + (size_t)qrow * p.d + col;
-                if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
-                    v = *reinterpret_cast<const f32x4*>(src);
-                } else {
+                for (int u = 0; u < PU; ++u) {
+                    int s = s0 + WPS * u;
+                    va[u] = vb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (s < S && qrow < p.nq) {
+                        s += rot;
+                        s = s >= S ? s - S : s;
+                        const int col = 16 * s + 8 * hh;
+                        if (q_vec && col + 7 < p.d) {
+                            va[u] = *reinterpret_cast<const f32x4*>(qbase + col);
+                            vb[u] = *reinterpret_cast<const f32x4*>(qbase + col + 4);
+                        } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (col + j < p.d) v[j] = src[j];
+                            for (int j = 0; j < 4; ++j) {
+                                if (col + j < p.d) va[u][j] = qbase[col + j];
+                                if (col + 4 + j < p.d) vb[u][j] = qbase[col + 4 + j];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    int s = s0 + WPS * u;
+                    if (s < S) {
+                        s += rot;
+                        s = s >= S ? s - S : s;
+                        f16x8 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = (_Float16)(va[u][j] * qsc);
+                            v[4 + j] = (_Float16)(vb[u][j] * qsc);
+                        }
+                        qf[s * 64 + lane] = __builtin_bit_cast(f32x4, v);
+                    }
                 }
             }
-            qf[idx] = v;
+        } else {
+            // fragment (s, l) = Q[l&31][col0 + 8s + 4(l>>5) .. +3]
+            const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
+            const float* qbase = p.Q + (size_t)(qrow < p.nq ? qrow : 0) * p.d;
+            for (int s0 = wave; s0 < S; s0 += WPS * PU) {
+                f32x4 v[PU];
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    int s = s0 + WPS * u;
+                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (s < S && qrow < p.nq) {
+                        s += rot;
+                        s = s >= S ? s - S : s;
+                        const int col = p.col0 + 8 * s + 4 * hh;
+                        if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
+                            v[u] = *reinterpret_cast<const f32x4*>(qbase + col);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (col + j < p.d) v[u][j] = qbase[col + j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PU; ++u) {
+                    int s = s0 + WPS * u;
+                    if (s < S) {
+                        s += rot;
+                        s = s >= S ? s - S : s;
+                        qf[s * 64 + lane] = v[u];
+                    }
+                }
+            }
         }
     }
     if (tid < kQT) {
         cnt[tid] = 0;
         // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
         // they never enter the slow path (left at -inf they tie forever and double the scan time)
-        float t0 = -__builtin_inff();
+        float t0 = RAGK_SCORE_FLOOR;
         if (p.thr_key && tid < p.nq && p.thr_key[tid] != 0ull) {
             t0 = unord32((uint32_t)(p.thr_key[tid] >> 32));
             if (P == 1) t0 -= p.margin[tid];  // the band below an approximate score that k rows reach
         }
+        // L2 with ||q||^2 = inf / NaN: every distance is inf or NaN, which faiss's heap never admits
+        // (a NaN filter: `score >= NaN` is false for every score, +inf included)
+        if (L2 && tid < p.nq && !(p.qnorm[tid] <= 3.402823466e+38f)) t0 = __builtin_nanf("");
         thr[tid] = tid < p.nq ? t0 : __builtin_inff();
         if (P == 1) {
             mrg[tid] = tid < p.nq ? p.margin[tid] : 0.f;
@@ -242,33 +333,19 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     if (tid < 4) flag[tid] = 0;
     __syncthreads();
 
-    const long long last_row = p.n_rows - 1;
-    const long long tile_rows = (long long)kTileRows * p.tile_step;  // distance between consecutive tiles' first rows
-    const int tiles_per_iter = gridDim.x * kScanWaves;
-    int tile = blockIdx.x * kScanWaves + wave;
-    auto row_ptr = [&](int t) -> const float* {
-#if defined(RAGK_ABLATE_L2_WINDOW)
-        t &= 31;
-#endif
-        long long row = (long long)t * tile_rows + r;
-        row = row < last_row ? row : last_row;
-        return p.X + row * p.row_stride + p.col0 + 4 * h;
-    };
-
     const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
-    f32x4 xb[D];
-    const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
-#pragma unroll
-    for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+    // Warm start (k <= 16, 8-wave build, no sampled threshold): see the filter below.
+    const bool warm = kScanWaves == 8 && p.k <= 16 && !p.acc_out && p.thr_key == nullptr;
 
     // Overflow flags: pass number seq (one pass = one trip through the barrier loop below) owns
     // flag[seq & 3]; appends raise the flag of the pass that will check them, and pass seq clears
     // the slot of pass seq + 2, so a wave that has already left a pass never races a wave that is
     // still reading that pass's flag.
     uint32_t seq = 0;
-    for (int it = 0; it < p.n_iters; ++it, tile += tiles_per_iter) {
+    for (int it = 0; it < p.n_iters; ++it) {
+        tile = tile_of(it);
         const bool active = tile < p.n_tiles;  // wave-uniform
-        const int tnext = tile + tiles_per_iter;
+        const int tnext = it + 1 < p.n_iters ? tile_of(it + 1) : p.n_tiles;
         const float* pn = row_ptr(tnext < p.n_tiles ? tnext : p.n_tiles - 1);
 
         f32x16 acc;
@@ -371,6 +448,42 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
             for (int i = 0; i < 16; ++i) sc[i] = acc[i] + 0.0f;
         }
 
+        // ---- warm start.  A cold filter lets the first round's 256 rows per query into a 64-slot buffer:
+        // overflow, sort, retry — and again for the next three or four rounds, with the whole workgroup
+        // (and, since every workgroup starts together, the whole chip) parked at each sort: 40 us of a
+        // 0.71 ms scan of 1.25M x 768.  Instead, each lane posts the best eligible score of its 16 rows;
+        // the 16 half-tile maxima of a query come from 16 disjoint row sets, so at least k distinct rows
+        // reach the k-th largest of them and the filter may start there.  About 15 of the first 256 rows
+        // then pass and the first sort comes four rounds later, with a threshold from ~1300 rows.
+        if (warm && it == 0) {  // kernel-uniform
+            float* sub = reinterpret_cast<float*>(keys);  // the candidate buffers are still empty
+            float m = -__builtin_inff();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil) m = fmaxf(m, sc[i]);  // NaN never wins
+                }
+            }
+            sub[r * 16 + wave * 2 + h] = m;
+            __syncthreads();
+            {
+                const int q = tid >> 4, j = tid & 15;
+                const float v = sub[q * 16 + j];
+                int rank = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float o = sub[q * 16 + i];
+                    rank += (o > v || (o == v && i < j)) ? 1 : 0;
+                }
+                if (rank == p.k - 1) {
+                    const float cand = P == 1 ? v - mrg[q] : v;
+                    if (cand > thr[q]) thr[q] = cand;  // parked (+inf) and lossy queries stay parked
+                }
+            }
+            __syncthreads();
+        }
+
         // ---- filter + append
         uint32_t pending = 0;
         if (active) {
@@ -431,7 +544,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                             }
                             const bool full = nn[j] >= (uint32_t)p.k;
                             const float kscore = unord32((uint32_t)(kth >> 32));
-                            float tnew = full ? kscore - mrg[q] : -__builtin_inff();
+                            // never below the current filter (warm start / sampled start / earlier sorts):
+                            // every kept key already passed it, and a query sorted along with the others
+                            // before it holds k rows must not fall back to an open filter
+                            float tnew = full ? fmaxf(kscore - mrg[q], thr[q]) : thr[q];
                             uint32_t keep = 0;
 #pragma unroll
                             for (int e = 0; e < E; ++e) {
@@ -463,7 +579,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                             const int idx = e * 64 + lane;
                             if (idx < p.k) keys[(size_t)q * C + idx] = kk[j][e];
                             if (idx == p.k - 1)
-                                thr[q] = nn[j] >= (uint32_t)p.k ? unord32((uint32_t)(kk[j][e] >> 32)) : -__builtin_inff();
+                                if (nn[j] >= (uint32_t)p.k) thr[q] = unord32((uint32_t)(kk[j][e] >> 32));  // else: keep the filter
                         }
                         if (lane == 0) cnt[q] = min(nn[j], (uint32_t)p.k);
                     }
@@ -575,7 +691,7 @@ struct ShardListSrc {  // per-shard (score, id) results: shard l's element (q * 
     __device__ __forceinline__ u64 get(int q, int l, int pos) const {
         const size_t e = (size_t)q * k + pos;
         const long long id = ids[(size_t)l * id_stride + e];
-        if (id < 0) return 0ull;
+        if (id < 0 || id > 0xFFFFFFFEll) return 0ull;  // padding; ids beyond 32 bits cannot come from rag_index (set_id_offset refuses them)
         const float s = scores[(size_t)l * score_stride + e];
         return make_key(metric ? -s : s, (uint32_t)id);  // L2 lists carry ascending distances
     }
@@ -795,8 +911,6 @@ struct ScreenQueryState {   // per pass of <= 32 queries (device memory)
     float unscale[kQT];
     float margin[kQT];      // 2 eps (4 eps for L2 ranking scores)
     uint32_t lossy[kQT];    // certificate void: out-of-range query, or a workgroup dropped part of the band
-    uint32_t overflow[kQT]; // certificate void: the band did not fit the candidate list (screen_collect_kernel)
-    uint32_t count[kQT];    // candidates collected (packed at the front of the list)
     uint32_t sample_lossy[kQT];  // scratch for the sample pass (its lists only seed thresholds)
     uint32_t fallback[kQT]; // set by the finalize kernel: this query goes through the fp32 scan
     uint32_t any_fallback;  // the fallback launches read this word
@@ -868,37 +982,69 @@ __global__ __launch_bounds__(256) void screen_prep_kernel(const float* Q, int nq
     qs->fallback[q] = 0;
 }
 
-// Candidate collection.  Per query: (A) the k-th best approximate key over all workgroup lists, by
-// the same tournament as the merge kernel, k rounds; (B) every listed row whose approximate score is
-// within the query's margin of it, appended in arbitrary order (stage 2 ranks by exact key).  The
-// certificate needs the *whole* band: more than kp - 1 band rows, or a workgroup list that lies
-// entirely inside the band (it may have been cut at kout), void it.
-struct ScreenCandidates {
-    float* approx;        // [kQT][kp] approximate ranking scores
-    long long* rows;      // [kQT][kp] local row numbers, -1 = empty
-    uint32_t* overflow;   // [kQT] certificate void: band wider than kp or cut short
-    uint32_t* count;      // [kQT] candidates written
+// Resolve: what turns the screening pass's lists into results — ONE launch, one 256-thread workgroup per
+// query (it was three: collect, verify, finalize, 27 us of kernels plus two dependent-launch boundaries
+// of a 0.44 ms shard step; everything between the phases now stays in LDS).
+//   (A) the k-th best approximate key over all workgroup lists, by the same tournament as the merge
+//       kernel, k rounds;
+//   (B) every listed row whose approximate score is within the query's margin of it — the band — is a
+//       candidate.  The certificate needs the WHOLE band: more than kp - 1 band rows, or a workgroup list
+//       that lies entirely inside the band (it may have been cut at kout), void it;
+//   (C) canonical fp32 score of every candidate (the rago_dot chain of oracle/flat_oracle.c).  Each wave
+//       stages RPW candidate rows in LDS with coalesced 16-byte loads, all in flight together, then RPW
+//       lanes run the RPW fmaf chains side by side out of LDS; four waves cover 32 (16) candidates per
+//       pass, which is one pass for the usual dozen or two;
+//   (D) wave 0 checks the certificate, ranks the exact keys and writes (score, id); a query whose
+//       certificate failed raises the fallback words the fp32 scan launches read.
+struct ResolveParams {
+    KeyListSrc src;
+    int n_lists, k, kp, look;
+    const float* X;          // fp32 corpus
+    long long row_stride;
+    const float* xnorm;      // canonical squared norms (L2)
+    const float* Q;          // this pass's queries, [nq][d]
+    int d, d8, l2;
+    const float* qnorm;      // canonical ||q||^2 (L2)
+    long long id_offset;
+    ScreenQueryState* qs;
+    ScreenCounters* ctr;
+    float* out_s;            // [nq][k]
+    long long* out_i;
 };
 
-template <int OWN>
-__global__ __launch_bounds__(256) void screen_collect_kernel(const KeyListSrc src, const int n_lists, const int k,
-                                                             const int kp, const int look, const float* margin,
-                                                             const ScreenCandidates out) {
+__host__ __device__ inline int resolve_rows_per_wave(int d8) { return d8 <= 1024 ? 8 : 4; }
+__host__ __device__ inline size_t resolve_lds_bytes(int d8, int n_lists, int look, int kp) {
+    const size_t stage = (size_t)4 * resolve_rows_per_wave(d8) * (d8 + 4) * sizeof(float);
+    const size_t ahead = (size_t)n_lists * look * 8;
+    return (size_t)kp * 16 + (size_t)d8 * sizeof(float) + (stage > ahead ? stage : ahead);
+}
+
+template <int OWN, int RPW>
+__global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* ahead = reinterpret_cast<u64*>(smem);  // [n_lists][look], as in tournament_merge_kernel
+    u64* c_keys = reinterpret_cast<u64*>(smem);                   // [kp] exact ranking keys
+    uint32_t* c_rows = reinterpret_cast<uint32_t*>(c_keys + p.kp);  // [kp] local row numbers
+    float* c_approx = reinterpret_cast<float*>(c_rows + p.kp);      // [kp] approximate ranking scores
+    float* qv = c_approx + p.kp;                                    // [d8] the query, zero padded (kp * 16 bytes in: aligned)
+    u64* ahead = reinterpret_cast<u64*>(qv + p.d8);                 // [n_lists][look], phases A and B ...
+    float* rows = reinterpret_cast<float*>(qv + p.d8);              // ... then [4 waves][RPW][d8 + 4], phase C
     __shared__ u64 wmax[2][4];
     __shared__ uint32_t s_cnt, s_cut;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int kout = src.k;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_lists = p.n_lists, look = p.look, kp = p.kp, kout = p.src.k;
+
     for (int idx = tid; idx < n_lists * look; idx += 256) {
-        const int l = idx / look, p = idx - l * look;
-        ahead[idx] = src.get(q, l, p);
+        const int l = idx / look, pp = idx - l * look;
+        ahead[idx] = p.src.get(q, l, pp);
     }
+    for (int c = tid; c < p.d8; c += 256) qv[c] = c < p.d ? p.Q[(size_t)q * p.d + c] : 0.f;
     if (tid == 0) {
         s_cnt = 0;
         s_cut = 0;
     }
     __syncthreads();
+
+    // ---- (A) k-th best approximate key
     u64 head[OWN];
     int pos[OWN];
 #pragma unroll
@@ -908,177 +1054,133 @@ __global__ __launch_bounds__(256) void screen_collect_kernel(const KeyListSrc sr
         head[j] = l < n_lists ? ahead[(size_t)l * look] : 0ull;
     }
     u64 kth = 0ull;
-    for (int round = 0; round < k; ++round) {
+    for (int round = 0; round < p.k; ++round) {
         u64 best = head[0];
 #pragma unroll
         for (int j = 1; j < OWN; ++j) best = umax64(best, head[j]);
         const u64 wm = wave_max_u64(best);
-        if ((tid & 63) == 0) wmax[round & 1][tid >> 6] = wm;
+        if (lane == 0) wmax[round & 1][wave] = wm;
         __syncthreads();
         const u64 bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]),
                               umax64(wmax[round & 1][2], wmax[round & 1][3]));
         kth = bm;
-        if (bm == 0ull) break;  // fewer than k rows in all: everything listed is a candidate
+        if (bm == 0ull) break;  // fewer than k rows in all: everything listed is a candidate (workgroup-uniform)
         if (best == bm) {
 #pragma unroll
             for (int j = 0; j < OWN; ++j) {
                 if (head[j] == bm) {
                     const int l = tid + 256 * j;
                     const int np = ++pos[j];
-                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < kout ? src.get(q, l, np) : 0ull);
+                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < kout ? p.src.get(q, l, np) : 0ull);
                 }
             }
         }
     }
     __syncthreads();
-    const float thr = kth != 0ull ? unord32((uint32_t)(kth >> 32)) - margin[q] : -__builtin_inff();
+
+    // ---- (B) the band
+    const float margin = p.qs->margin[q];
+    const float thr = kth != 0ull ? unord32((uint32_t)(kth >> 32)) - margin : -__builtin_inff();
     for (int l = tid; l < n_lists; l += 256) {
-        int p = 0;
-        for (; p < kout; ++p) {
-            const u64 key = p < look ? ahead[(size_t)l * look + p] : src.get(q, l, p);
+        int pp = 0;
+        for (; pp < kout; ++pp) {
+            const u64 key = pp < look ? ahead[(size_t)l * look + pp] : p.src.get(q, l, pp);
             if (key == 0ull) break;
             const float a = unord32((uint32_t)(key >> 32));
             if (a < thr) break;
             const uint32_t slot = atomicAdd(&s_cnt, 1u);
             if (slot < (uint32_t)kp) {
-                out.approx[(size_t)q * kp + slot] = a;
-                out.rows[(size_t)q * kp + slot] = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+                c_approx[slot] = a;
+                c_rows[slot] = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
             }
         }
-        if (p == kout) s_cut = 1;  // the whole list is in the band: rows below its cut may be too
+        if (pp == kout) s_cut = 1;  // the whole list is in the band: rows below its cut may be too
     }
     __syncthreads();
-    const uint32_t n = s_cnt;
-    for (int i = (int)min(n, (uint32_t)kp) + tid; i < kp; i += 256) out.rows[(size_t)q * kp + i] = -1;
-    if (tid == 0) {
-        out.overflow[q] = (n >= (uint32_t)kp || s_cut) ? 1u : 0u;
-        out.count[q] = min(n, (uint32_t)kp);
-    }
-}
+    const int n = (int)min(s_cnt, (uint32_t)kp);                 // workgroup-uniform
+    const bool overflow = s_cnt >= (uint32_t)kp || s_cut != 0;
 
-// Exact second stage: canonical fp32 score of candidate (q, j), as a ranking key (0 for an empty slot).
-// One 64-thread workgroup stages 8 candidate rows in LDS with coalesced loads (all of a thread's loads
-// in flight together); 8 lanes then run the 8 fmaf chains (oracle/flat_oracle.c:rago_dot order) out
-// of LDS with 16-byte reads.
-constexpr int kVerifyRows = 8;
-__host__ __device__ inline size_t verify_lds_bytes(int d8) {
-    return ((size_t)kVerifyRows * (d8 + 4) + d8) * sizeof(float);
-}
-
-// DQ = ceil(d8 / 1024): a thread holds 32 float4 of candidate rows at a time, i.e. all eight rows of the
-// group for d <= 1024, four rows per pass for d <= 2048.
-template <int DQ>
-__global__ __launch_bounds__(64) void screen_verify_kernel(const float* X, long long row_stride, const float* xnorm,
-                                                           const float* Q, int d, int d8, int l2, int kp,
-                                                           const long long* cand_rows, u64* exact_keys) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* rows = reinterpret_cast<float*>(smem);
-    float* qv = rows + (size_t)kVerifyRows * (d8 + 4);
-    const int q = blockIdx.y, c0 = blockIdx.x * kVerifyRows, tid = threadIdx.x;
-    long long my_id = -1;
-    if (tid < kVerifyRows && c0 + tid < kp) my_id = cand_rows[(size_t)q * kp + c0 + tid];
-    if (__ballot(my_id >= 0) == 0ull) {  // nothing to score in this group
-        if (tid < kVerifyRows && c0 + tid < kp) exact_keys[(size_t)q * kp + c0 + tid] = 0ull;
-        return;
-    }
-    const int d4 = d8 / 4;  // <= 256 * DQ
-    constexpr int RP = kVerifyRows / DQ, NU = 4 * DQ;
-    {   // a pass's row loads are all issued before its first LDS store (one memory latency per pass)
-        float qreg[16 * DQ];
+    // ---- (C) canonical scores.  d8 / 4 <= 32 * 64 / RPW float4 per row: a lane holds NU of each of its wave's rows.
+    constexpr int NU = 32 / RPW;
+    const int d4 = p.d8 / 4;
+    float* wrows = rows + (size_t)wave * RPW * (p.d8 + 4);
+    for (int base = 0; base < n; base += 4 * RPW) {
+        __syncthreads();  // the staging area is free: phase B (first pass) or the previous pass's chains are done
+        const int g0 = base + wave * RPW;
+        {
+            f32x4 v[RPW][NU];
 #pragma unroll
-        for (int u = 0; u < 16 * DQ; ++u) {
-            const int c = tid + 64 * u;
-            qreg[u] = c < d ? Q[(size_t)q * d + c] : 0.f;
-        }
-#pragma unroll
-        for (int pass = 0; pass < DQ; ++pass) {
-            f32x4 v[RP][NU];
-#pragma unroll
-            for (int j = 0; j < RP; ++j) {
-                const long long id = __shfl(my_id, pass * RP + j, 64);
-                const f32x4* src = reinterpret_cast<const f32x4*>(X + (id < 0 ? 0 : id) * row_stride);
+            for (int j = 0; j < RPW; ++j) {
+                const bool have = g0 + j < n;  // wave-uniform
+                const f32x4* src = reinterpret_cast<const f32x4*>(p.X + (long long)(have ? c_rows[g0 + j] : 0u) * p.row_stride);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int c = tid + 64 * u;
-                    v[j][u] = (id >= 0 && c < d4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int c = lane + 64 * u;
+                    v[j][u] = (have && c < d4) ? src[c] : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
 #pragma unroll
-            for (int j = 0; j < RP; ++j) {
-                f32x4* dst = reinterpret_cast<f32x4*>(rows + (size_t)(pass * RP + j) * (d8 + 4));
+            for (int j = 0; j < RPW; ++j) {
+                f32x4* dst = reinterpret_cast<f32x4*>(wrows + (size_t)j * (p.d8 + 4));
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const int c = tid + 64 * u;
+                    const int c = lane + 64 * u;
                     if (c < d4) dst[c] = v[j][u];
                 }
             }
         }
+        __syncthreads();
+        if (lane < RPW && g0 + lane < n) {
+            const uint32_t my_row = c_rows[g0 + lane];
+            const f32x4* x4 = reinterpret_cast<const f32x4*>(wrows + (size_t)lane * (p.d8 + 4));
+            const f32x4* q4 = reinterpret_cast<const f32x4*>(qv);
+            float acc = 0.f;
+            f32x4 xa = x4[0], xb = x4[1], qa = q4[0], qb = q4[1];
+            for (int s = 2; s <= d4; s += 2) {  // operands of the next group are read under this group's chain
+                const int sn = s < d4 ? s : 0;
+                const f32x4 xa_n = x4[sn], xb_n = x4[sn + 1], qa_n = q4[sn], qb_n = q4[sn + 1];
 #pragma unroll
-        for (int u = 0; u < 16 * DQ; ++u) {
-            const int c = tid + 64 * u;
-            if (c < d8) qv[c] = qreg[u];
+                for (int t = 0; t < 4; ++t) {
+                    acc = __builtin_fmaf(xa[t], qa[t], acc);
+                    acc = __builtin_fmaf(xb[t], qb[t], acc);
+                }
+                xa = xa_n;
+                xb = xb_n;
+                qa = qa_n;
+                qb = qb_n;
+            }
+            float score = acc + 0.0f;
+            if (p.l2) score = __builtin_fmaf(2.0f, acc, -p.xnorm[my_row]) + 0.0f;
+            c_keys[g0 + lane] = make_key(score, my_row);
         }
     }
     __syncthreads();
-    if (tid >= kVerifyRows || c0 + tid >= kp) return;
-    u64 key = 0ull;
-    if (my_id >= 0) {
-        const f32x4* x4 = reinterpret_cast<const f32x4*>(rows + (size_t)tid * (d8 + 4));
-        const f32x4* q4 = reinterpret_cast<const f32x4*>(qv);
-        float acc = 0.f;
-        f32x4 xa = x4[0], xb = x4[1], qa = q4[0], qb = q4[1];
-        for (int s = 2; s <= d4; s += 2) {  // operands of the next group are read under this group's chain
-            const int sn = s < d4 ? s : 0;
-            const f32x4 xa_n = x4[sn], xb_n = x4[sn + 1], qa_n = q4[sn], qb_n = q4[sn + 1];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc = __builtin_fmaf(xa[t], qa[t], acc);
-                acc = __builtin_fmaf(xb[t], qb[t], acc);
-            }
-            xa = xa_n;
-            xb = xb_n;
-            qa = qa_n;
-            qb = qb_n;
-        }
-        float score = acc + 0.0f;
-        if (l2) score = __builtin_fmaf(2.0f, acc, -xnorm[my_id]) + 0.0f;
-        key = make_key(score, (uint32_t)my_id);
-    }
-    exact_keys[(size_t)q * kp + c0 + tid] = key;
-}
+    if (wave != 0) return;
 
-// One wave per query: certificate, rank the exact keys, write the results.  kp <= 256; the usual few
-// dozen candidates take the one-key-per-lane sort.
-__global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx, const long long* cand_rows,
-                                                             const u64* exact_keys, const uint32_t* overflow, int kp,
-                                                             int k, int l2, const float* qnorm, long long id_offset,
-                                                             ScreenQueryState* qs, ScreenCounters* ctr, float* out_s,
-                                                             long long* out_i) {
+    // ---- (D) certificate, ranking, results: one wave, kp <= 256 keys (the usual few dozen take the
+    // one-key-per-lane sort)
     constexpr int E = 4;
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const uint32_t cnt = qs->count[q];  // wave-uniform
     u64 kk[1][E];
     float worst = 0.f;
-    const float margin = qs->margin[q];
-    const float eps = margin * (l2 ? 0.25f : 0.5f);
+    const float eps = margin * (p.l2 ? 0.25f : 0.5f);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = e * 64 + lane;
         u64 key = 0ull;
-        if ((uint32_t)idx < cnt && cand_rows[(size_t)q * kp + idx] >= 0) {
-            key = exact_keys[(size_t)q * kp + idx];
+        if (idx < n) {
+            key = c_keys[idx];
             const float ex = unord32((uint32_t)(key >> 32));
-            const float err = fabsf(approx[(size_t)q * kp + idx] - ex) * (l2 ? 0.5f : 1.f);
+            const float err = fabsf(c_approx[idx] - ex) * (p.l2 ? 0.5f : 1.f);
             worst = fmaxf(worst, err);
         }
         kk[0][e] = key;
     }
     worst = wave_max_f32(worst);
-    // certificate: the scan kept the whole band (not lossy), the collection held it (no overflow), and —
-    // belt and braces — no verified candidate shows an error beyond the bound the band was built from
-    bool ok = qs->lossy[q] == 0 && overflow[q] == 0;
+    // the scan kept the whole band (not lossy), this kernel held it (no overflow), and — belt and braces —
+    // no verified candidate shows an error beyond the bound the band was built from
+    bool ok = p.qs->lossy[q] == 0 && !overflow;
     if (ok && !(worst <= eps)) ok = false;  // also catches eps == 0 with any error, and NaN
-    if (cnt <= 64u) {
+    if (n <= 64) {
         u64 k1[1][1] = {{kk[0][0]}};
         wave_sort_desc<1, 1>(k1, lane);
         kk[0][0] = k1[0][0];
@@ -1088,35 +1190,35 @@ __global__ __launch_bounds__(64) void screen_finalize_kernel(const float* approx
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int idx = e * 64 + lane;
-        if (idx < k) {
+        if (idx < p.k) {
             const u64 key = kk[0][e];
-            float s;
+            float sc;
             long long id;
             if (key == 0ull) {
-                s = l2 ? 3.402823466e+38f : -3.402823466e+38f;
+                sc = p.l2 ? 3.402823466e+38f : -3.402823466e+38f;
                 id = -1;
             } else {
                 const float rs = unord32((uint32_t)(key >> 32));
-                if (l2) {
-                    const float dist = qnorm[q] - rs;
-                    s = dist < 0.f ? 0.f : dist;
+                if (p.l2) {
+                    const float dist = p.qnorm[q] - rs;
+                    sc = dist < 0.f ? 0.f : dist;
                 } else {
-                    s = rs;
+                    sc = rs;
                 }
-                id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + id_offset;
+                id = (long long)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull)) + p.id_offset;
             }
-            out_s[(size_t)q * k + idx] = s;
-            out_i[(size_t)q * k + idx] = id;
+            p.out_s[(size_t)q * p.k + idx] = sc;
+            p.out_i[(size_t)q * p.k + idx] = id;
         }
     }
     if (lane == 0) {
-        atomicAdd(&ctr->queries, 1ull);
+        atomicAdd(&p.ctr->queries, 1ull);
         if (!ok) {
-            qs->fallback[q] = 1;
-            atomicOr(&qs->any_fallback, 1u);
-            atomicAdd(&ctr->fallbacks, 1ull);
+            p.qs->fallback[q] = 1;
+            atomicOr(&p.qs->any_fallback, 1u);
+            atomicAdd(&p.ctr->fallbacks, 1ull);
         } else if (eps > 0.f) {
-            atomicMax(&ctr->max_err_ratio_bits, __float_as_uint(worst / eps));
+            atomicMax(&p.ctr->max_err_ratio_bits, __float_as_uint(worst / eps));
         }
     }
 }

@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "flat_kernels.hip.h"
@@ -125,6 +127,21 @@ ScanFn scan_fn(int waves, int cap, int ring, bool l2) {
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel, size) instead of on every
+// launch: the call takes the runtime's global lock and showed up between the launches of a search.
+int ensure_dyn_lds(const void* fn, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    RAGC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = granted[{dev, fn}];
+    if (lds <= have) return RAG_OK;
+    RAGC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    have = lds;
+    return RAG_OK;
+}
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -177,7 +194,6 @@ struct rag_index {
     ragk::ScreenCorpusStats* sc_stats = nullptr;
     ragk::ScreenQueryState* sq = nullptr;
     ragk::ScreenCounters* sctr = nullptr;
-    float* cand_s = nullptr; long long* cand_i = nullptr; ragk::u64* cand_keys = nullptr; size_t cand_cap = 0;
 
     // sample pass (starting thresholds for k >= kSampleMinK)
     ragk::u64* sample_heads = nullptr;  // kQT x kSampleLists workgroup maxima
@@ -350,11 +366,12 @@ int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_
     ss.kout = 1;
     ss.n_tiles = lists * 8;
     ss.n_iters = 1;
+    ss.n_full = 1;
     ss.tile_step = (int)(base.n_tiles / ss.n_tiles);
     ss.thr_key = nullptr;
     ss.enable = nullptr;
     if (ss.lossy) ss.lossy = h->sq->sample_lossy;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipLaunchKernelGGL(fn, dim3(lists), dim3(8 * 64), lds, st, ss);
     HIP_TRY(hipGetLastError());
     sample_threshold_kernel<<<dim3(nq), dim3(64), 0, st>>>(h->sample_heads, lists, k, h->thr_keys);
@@ -404,6 +421,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         ScanParams sp;
         sp.X = h->X;
         sp.xnorm = h->xnorm;
+        sp.qnorm = h->qnorm;
         sp.Q = q_dev;
         sp.partial = h->partial;
         sp.ceil = ceil;
@@ -420,6 +438,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.k = k;
         sp.n_tiles = n_tiles;
         sp.n_iters = n_iters;
+        sp.n_full = n_tiles / (grid * waves);
         sp.enable = enable;
         sp.thr_key = sampled ? h->thr_keys : nullptr;
         sp.tile_step = 1;
@@ -456,7 +475,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         const ScanParams sp = make_params(col0, dc8);
         ScanFn fn = scan_fn(waves, cap, ring, l2);
         const size_t lds = scan_lds_bytes(dc8, cap);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
         HIP_TRY(hipGetLastError());
     }
@@ -534,19 +553,6 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
 
     int rc = ensure_search_ws(h, nb, kp, grid);
     if (rc) return rc;
-    const size_t cand = (size_t)kQT * kp;
-    if (cand > h->cand_cap) {
-        void* old[] = {h->cand_s, h->cand_i, h->cand_keys};
-        for (void* p : old)
-            if (p) (void)hipFree(p);
-        h->cand_s = nullptr;
-        h->cand_i = nullptr;
-        h->cand_keys = nullptr;
-        h->cand_cap = 0;
-        if ((rc = dev_alloc(&h->cand_s, cand)) || (rc = dev_alloc(&h->cand_i, cand)) || (rc = dev_alloc(&h->cand_keys, cand)))
-            return rc;
-        h->cand_cap = cand;
-    }
     if (l2) {
         row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(qp, h->d, h->d, 0, nb, h->qnorm);
         HIP_TRY(hipGetLastError());
@@ -560,6 +566,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     ScanParams sp;
     sp.X = reinterpret_cast<const float*>(h->X16);
     sp.xnorm = h->xnorm;
+    sp.qnorm = h->qnorm;
     sp.Q = qp;
     sp.partial = h->partial;
     sp.ceil = nullptr;
@@ -576,10 +583,14 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.k = k;
     sp.n_tiles = n_tiles;
     sp.n_iters = n_iters;
+    sp.n_full = n_tiles / (grid * waves);
     sp.enable = nullptr;
     sp.thr_key = nullptr;
     sp.tile_step = 1;
-    sp.kout = kp;
+    // keys a workgroup emits per query: its LDS buffer never holds more than `cap`, so longer lists would
+    // be zero padding (at kp = 240 that was 15.7 MB of zeros written per batch and left dirty in L2)
+    const int kout = std::min(kp, cap);
+    sp.kout = kout;
     sp.qscale = h->sq->qscale;
     sp.unscale = h->sq->unscale;
     sp.margin = h->sq->margin;
@@ -595,7 +606,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     if (waves == 12) fn = screen_fn12(l2);
 #endif
     const size_t lds = scan_lds_bytes(h->d64 / 2, cap);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         HIP_TRY(hipEventCreate(&e0));
@@ -609,24 +620,41 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         prof_push(h, e0, e1);
     }
 
-    // the band below the k-th best approximate key of every query -> (approximate ranking score, local row)
-    KeyListSrc src{h->partial, grid, kp};
-    ScreenCandidates cands{h->cand_s, h->cand_i, h->sq->overflow, h->sq->count};
-    const int look = merge_look(grid, kp, k);
-    auto collect = grid <= 256 ? screen_collect_kernel<1> : (grid <= 512 ? screen_collect_kernel<2> : screen_collect_kernel<kMergeMaxOwned>);
-    collect<<<dim3(nb), dim3(256), (size_t)grid * look * 8, st>>>(src, grid, k, kp, look, h->sq->margin, cands);
-    HIP_TRY(hipGetLastError());
-
-    // stage 2: canonical fp32 scores of the candidates, certificate, results
-    const size_t vlds = verify_lds_bytes(h->d8);
-    auto verify = h->d8 <= 1024 ? screen_verify_kernel<1> : screen_verify_kernel<2>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(verify), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
-    verify<<<dim3((kp + kVerifyRows - 1) / kVerifyRows, nb), dim3(64), vlds, st>>>(
-        h->X, h->d8, h->xnorm, qp, h->d, h->d8, l2 ? 1 : 0, kp, h->cand_i, h->cand_keys);
-    HIP_TRY(hipGetLastError());
-    screen_finalize_kernel<<<dim3(nb), dim3(64), 0, st>>>(h->cand_s, h->cand_i, h->cand_keys, h->sq->overflow, kp, k,
-                                                          l2 ? 1 : 0, h->qnorm, h->id_offset, h->sq, h->sctr, os, oi);
-    HIP_TRY(hipGetLastError());
+    // resolve: band below the k-th best approximate key -> canonical fp32 scores -> certificate -> results
+    {
+        const int look = merge_look(grid, kout, k);
+        ResolveParams rp;
+        rp.src = KeyListSrc{h->partial, grid, kout};
+        rp.n_lists = grid;
+        rp.k = k;
+        rp.kp = kp;
+        rp.look = look;
+        rp.X = h->X;
+        rp.row_stride = h->d8;
+        rp.xnorm = h->xnorm;
+        rp.Q = qp;
+        rp.d = h->d;
+        rp.d8 = h->d8;
+        rp.l2 = l2 ? 1 : 0;
+        rp.qnorm = h->qnorm;
+        rp.id_offset = h->id_offset;
+        rp.qs = h->sq;
+        rp.ctr = h->sctr;
+        rp.out_s = os;
+        rp.out_i = oi;
+        const size_t rlds = resolve_lds_bytes(h->d8, grid, look, kp);
+        using ResolveFn = void (*)(const ResolveParams);
+        ResolveFn resolve;
+        if (h->d8 <= 1024)
+            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<1, 8>
+                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 8> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 8>);
+        else
+            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<1, 4>
+                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 4> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 4>);
+        if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(resolve), rlds))) return rc;
+        hipLaunchKernelGGL(resolve, dim3(nb), dim3(256), rlds, st, rp);
+        HIP_TRY(hipGetLastError());
+    }
 
     // fallback: the fp32 search of this block, enqueued unconditionally, a no-op unless a certificate failed
     return search_exact_block(h, qp, nb, k, os, oi, st, &h->sq->any_fallback, h->sq->fallback);
@@ -732,7 +760,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.second);
         }
         void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev,
-                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr, h->cand_s, h->cand_i, h->cand_keys};
+                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
@@ -757,6 +785,9 @@ extern "C" int rag_index_add(rag_index* h, const float* rows_host, int64_t n) {
     if (!h || n < 0 || (n > 0 && !rows_host)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
     if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
+                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = grow_rows(h, h->n + n);
@@ -776,6 +807,9 @@ extern "C" int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t
     if (!h || n < 0 || (n > 0 && !rows_dev)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
     if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
+                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = grow_rows(h, h->n + n);
@@ -796,6 +830,9 @@ extern "C" int rag_index_add_synthetic(rag_index* h, int64_t n, uint64_t seed, i
     if (!h || n < 0) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
     if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
+                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     int rc = grow_rows(h, h->n + n);
@@ -831,7 +868,14 @@ extern "C" int32_t rag_index_metric(const rag_index* h) { return h ? h->metric :
 
 extern "C" int rag_index_set_id_offset(rag_index* h, int64_t id_offset) {
     if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    // the ranking keys of the shard merge carry the GLOBAL id in 32 bits (flat_kernels.hip.h ShardListSrc):
+    // an offset that can push an id past 2^32 - 2 would wrap there without a trace
+    if (id_offset < 0 || id_offset > 0xFFFFFFFEll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld outside [0, 2^32-2]: global ids must fit 32 bits", (long long)id_offset);
     std::lock_guard<std::mutex> lk(h->mu);
+    if (id_offset + h->n > 0xFFFFFFFFll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
+                    (long long)id_offset, h->n);
     h->id_offset = id_offset;
     return RAG_OK;
 }

@@ -232,7 +232,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     ep.ln_g = w[3]; ep.ln_b = w[4];
     ep.out = h->x;
     ep.T = T; ep.nseq = nseq; ep.H = H; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
-    ep.vocab = c.vocab_size; ep.eps = c.ln_eps;
+    ep.vocab = c.vocab_size; ep.type_vocab = c.type_vocab > 0 ? c.type_vocab : 1; ep.eps = c.ln_eps;
     embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
     RAGC_HIP_TRY(hipGetLastError());
 

@@ -1,11 +1,12 @@
 """Ablations of the scan kernel: matrix work removed (load stream only) / corpus cache-resident
 (matrix pipe only), timed against the product build, one subprocess per library."""
 import os, sys, subprocess
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts._sidelib import build
+os.environ["RAG_REPO_ROOT"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
 import os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.environ["RAG_REPO_ROOT"])
 import numpy as np
 from rag_inference_pipeline_amd.flat_index import FlatIndex
 from oracle import flat as oracle

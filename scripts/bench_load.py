@@ -1,7 +1,7 @@
 """Load-time check: FAISSStore.load() of a flat index file (read + host->device), rows/s and GB/s."""
 import os, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import flat as oracle
 from rag_inference_pipeline_amd import index_io
 from rag_inference_pipeline_amd.components.faiss_store import FAISSStore

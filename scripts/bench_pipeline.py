@@ -1,3 +1,4 @@
+import os
 """Whole retrieval-node batch (BASELINE configs[1] / [2]) through the Python components and the
 executor: text queries -> encoder -> 1M x 384 scan + top-k -> SQLite document fetch -> (cross-encoder).
 Reports per-stage wall time from the executor's stage timers and batches/s; this is where host-side
@@ -7,7 +8,7 @@ costs (tokenisation, document objects) show up next to the kernels.
 """
 import argparse, os, sqlite3, sys, tempfile, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rag_inference_pipeline_amd.batch_scheduler import Batch
 from rag_inference_pipeline_amd.component_registry import ComponentRegistry
 from rag_inference_pipeline_amd.components.document_store import DocumentStore

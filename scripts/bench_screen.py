@@ -1,8 +1,9 @@
+import os
 """Two-stage search vs the one-pass fp32 scan on the same synthetic corpus: wall time per batch,
 stage-1 kernel time (HIP events), certificate counters, and a result comparison."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rag_inference_pipeline_amd.flat_index import FlatIndex, SCREEN_FP16, SCREEN_OFF
 from oracle import flat as oracle
 

@@ -1,3 +1,4 @@
+import os
 """Stage timings of the transformer side (query encoder / cross-encoder) with GEMM flop accounting
 and the torch-CPU oracle timed beside each stage on a bounded sample.
 
@@ -5,7 +6,7 @@ and the torch-CPU oracle timed beside each stage on a bounded sample.
 """
 import argparse, json, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rag_inference_pipeline_amd import _native
 from rag_inference_pipeline_amd.bert import BertConfig, BertModel, random_weights, pack_sequences

@@ -1,3 +1,4 @@
+import os
 """Parity report for the flat search at scale (SURVEY.md §7 "hard parts"): the GPU result against
 (1) the CPU oracle — must be bit-identical — and (2) a float64 ranking of the same corpus, where any
 difference is classified as a near-tie (adjacent float64 scores closer than fp32 summation noise) or a
@@ -8,7 +9,7 @@ and this kernel approximate.
 """
 import argparse, json, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import flat as oracle
 from rag_inference_pipeline_amd.flat_index import FlatIndex
 

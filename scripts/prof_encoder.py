@@ -1,5 +1,6 @@
+import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["x"]
 import numpy as np
 import scripts.bench_stages as bs

@@ -1,7 +1,8 @@
+import os
 """Scratch timing of the flat scan (kernel time from HIP events + wall)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rag_inference_pipeline_amd.flat_index import FlatIndex
 from oracle import flat as oracle
 

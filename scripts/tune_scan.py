@@ -1,7 +1,7 @@
 """Interleaved A/B timing of scan-kernel launch geometries (one process, one index)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts._sidelib import build
 os.environ["RAG_AMD_LIB"] = build("TUNING", ["RAGK_TUNING"])  # 12/16-wave and ring-12/16 variants + env overrides
 from rag_inference_pipeline_amd.flat_index import FlatIndex

@@ -2,7 +2,7 @@
 +2.4 % at 1.25M — not adopted, it would double the P = 1 kernel instantiations for that)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts._sidelib import build
 os.environ["RAG_AMD_LIB"] = build("TUNING", ["RAGK_TUNING"])
 from rag_inference_pipeline_amd.flat_index import FlatIndex, SCREEN_FP16

@@ -5,6 +5,9 @@ argv: mode (cpu|gpu) rank world port out_path n d nq k metric
        path never does) and the merge is oracle.merge — this rehearses sharding, packing and the
        gloo all-gather with no GPU.
   gpu: the real FlatIndex and the device merge kernel; ranks share GPU 0, gather staged over gloo.
+  nccl: the product's multi-GPU configuration — backend "nccl" (= RCCL), rank r on GPU r, the packed
+       buffer gathered device-to-device by all_gather_into_tensor and merged in place by
+       rag_merge_topk_packed_device; also drives the leader path (head + query broadcast on the device).
 """
 import ctypes
 import os
@@ -25,7 +28,12 @@ def main() -> None:
     from oracle import flat as oracle
     from rag_inference_pipeline_amd.sharded import ShardedFlatIndex, shard_range
 
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if mode == "nccl":
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lo, hi = shard_range(n, rank, world)
     X_local = oracle.synth_rows(1234, lo, hi - lo, d)
     Q = oracle.synth_rows(4321, 0, nq, d)
@@ -47,15 +55,25 @@ def main() -> None:
     else:
         from rag_inference_pipeline_amd.flat_index import FlatIndex
 
-        torch.cuda.set_device(0)
-        local = FlatIndex(d, metric, device=0)
+        dev = torch.cuda.current_device() if mode == "nccl" else 0
+        torch.cuda.set_device(dev)
+        local = FlatIndex(d, metric, device=dev)
         local.add_synthetic(hi - lo, 1234, row_number_offset=lo)
         local.set_id_offset(lo)
-        sharded = ShardedFlatIndex(local, metric, device=0)
+        sharded = ShardedFlatIndex(local, metric, device=dev)
+        assert sharded.backend == ("nccl" if mode == "nccl" else "gloo"), sharded.backend
 
     D, I = sharded.search(Q, k)
     D2, I2 = sharded.search(Q[: max(1, nq // 2)], k)  # a second shape re-uses the group
-    np.savez(out_path, D=D, I=I, D2=D2, I2=I2, lo=lo, hi=hi)
+    extra = {}
+    if mode == "nccl":  # the serving protocol over RCCL: control words and the batch travel on the device
+        if rank == 0:
+            D3, I3 = sharded.leader_search(Q, k)
+            sharded.shutdown()
+            extra = dict(D3=D3, I3=I3)
+        else:
+            extra = dict(served=sharded.follower_loop())
+    np.savez(out_path, D=D, I=I, D2=D2, I2=I2, lo=lo, hi=hi, **extra)
     dist.barrier()
     dist.destroy_process_group()
 

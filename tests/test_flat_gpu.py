@@ -43,6 +43,11 @@ CASES = [
     (600_000, 64, 32, 100, 0),    # k >= 32 on a large corpus: thresholds seeded by the sample pass
     (700_001, 40, 9, 40, 1),      # same, L2, ragged
     (600_000, 64, 5, 300, 0),     # sample pass inside key-ceiling rounds
+    (65_536 + 32 * 151, 64, 32, 10, 0),   # 1 full round + 151 leftover tiles: the one-per-workgroup tail round
+    (65_536 * 2 + 32 * 700 + 5, 32, 9, 10, 1),  # 700 leftover tiles: waves 0..2 of the tail round, ragged last tile
+    (30_000, 384, 32, 250, 0),    # second key-ceiling round has k = 10: warm start under a ceiling
+    (4096, 768, 32, 16, 0),       # k = 16: the largest warm-start k (16 half-tile maxima)
+    (300, 768, 32, 10, 0),        # fewer tiles than waves: inactive waves post -inf maxima
 ]
 
 
@@ -129,6 +134,85 @@ def test_incremental_add_and_id_offset(gpu_required):
     Do, Io = oracle.search(X, Q, 10, id_offset=1_000_000)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
+
+
+def _nonfinite_case(metric):
+    rng = np.random.default_rng(77 + metric)
+    N, d, nq = 6000, 72, 12
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    X[5, 3] = np.nan                     # NaN row: every score NaN -> never a result
+    X[6, :] = np.inf                     # +inf / NaN scores depending on the query's signs
+    X[7, 0] = -np.inf
+    X[8, :] = 3.0e38                     # overflows to +-inf (or inf - inf = NaN) in the sum
+    X[9, 10] = np.inf; X[9, 11] = -np.inf
+    X[4000:4004, 1] = np.inf             # equal +inf scores: ties by id
+    Q[0, :] = 0.0                        # 0 * inf = NaN for the inf rows, exact zeros elsewhere
+    Q[1, 5] = np.nan                     # NaN query: no result at all
+    Q[2, 0] = np.inf
+    Q[3, :] = np.abs(Q[3, :])            # all positive: row 6 scores +inf and must rank first
+    Q[4, :] = 3.0e38
+    return X, Q
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_nonfinite_rows_and_queries_follow_the_faiss_heap_rule(gpu_required, metric, two_stage):
+    """include/rag_amd.h, "Non-finite values": a row whose ranking score is NaN, -inf or -FLT_MAX is never
+    returned (faiss's heap admits only strictly-better-than-neutral candidates), +inf ranks first, ties by
+    id; a NaN query gets k padding slots.  Bit-exact against the oracle, with the two-stage search
+    requested as well (a non-finite corpus switches it to inactive, so the fp32 scan answers)."""
+    from rag_inference_pipeline_amd.flat_index import SCREEN_INACTIVE
+    X, Q = _nonfinite_case(metric)
+    idx = _index(X, metric)
+    if two_stage:
+        idx.set_screening(True)
+        assert idx.screening == SCREEN_INACTIVE
+    for k in (10, 100):
+        D, I = idx.search(Q, k)
+        Do, Io = oracle.search(X, Q, k, metric)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+        assert not np.isnan(D).any() and 5 not in I
+        assert (I[1] == -1).all()                                  # NaN query
+    idx.close()
+
+
+def test_nonfinite_queries_on_a_finite_corpus_through_the_two_stage_search(gpu_required):
+    """A finite corpus keeps the fp16 screening copy; NaN / inf / huge queries fail the screening
+    certificate by construction and are answered by the fp32 fallback — same bits as the oracle."""
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16
+    rng = np.random.default_rng(5)
+    X, Q = _unit(rng, 40_000, 128), _unit(rng, 32, 128)
+    Q[3, 7] = np.nan
+    Q[9, 0] = np.inf
+    Q[17, :] = -np.inf
+    Q[21, :] *= 1.0e30
+    idx = _index(X)
+    idx.set_screening(True)
+    assert idx.screening == SCREEN_FP16
+    D, I = idx.search(Q, 10)
+    Do, Io = oracle.search(X, Q, 10)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    st = idx.screen_stats()
+    assert st["fallbacks"] >= 3
+    idx.close()
+
+
+def test_global_ids_must_fit_32_bits(gpu_required):
+    """the shard merge carries the global id in 32 bits — an offset that could wrap is refused."""
+    from rag_inference_pipeline_amd import _native
+    from rag_inference_pipeline_amd.flat_index import FlatIndex
+    idx = FlatIndex(16)
+    idx.add(np.zeros((100, 16), np.float32))
+    idx.set_id_offset(2**32 - 101)                      # last id = 2^32 - 2: fine
+    for bad in (2**32 - 50, 2**32, -1, 2**40):
+        with pytest.raises(_native.RagAmdError):
+            idx.set_id_offset(bad)
+    with pytest.raises(_native.RagAmdError):            # growing past the limit under a set offset
+        idx.add(np.zeros((5, 16), np.float32))
+    idx.close()
 
 
 def test_hip_reproduces_committed_golden(gpu_required):

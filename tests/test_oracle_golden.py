@@ -91,3 +91,39 @@ def test_synthetic_rows_are_unit_norm_and_position_independent():
     b = oracle.synth_rows(1234, 32, 32, 768)
     np.testing.assert_array_equal(a[32:], b)
     assert np.abs(np.linalg.norm(a.astype(np.float64), axis=1) - 1).max() < 1e-6
+
+
+def test_oracle_nonfinite_scores_follow_the_faiss_heap_rule():
+    """faiss IndexFlat.search selects with a heap that starts at -FLT_MAX (IP) / +FLT_MAX (L2) and admits a
+    candidate only if it compares strictly better than the heap top (published behaviour of
+    faiss/utils/Heap.h + the flat result handlers; call site faiss_store.py:152).  Restated literally
+    here in numpy over the oracle's own score matrix: NaN, -inf and -FLT_MAX never enter, +inf ranks
+    first, the rest is ordinary ordering."""
+    rng = np.random.default_rng(0)
+    N, d, nq, k = 500, 24, 6, 8
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    Q = rng.standard_normal((nq, d), dtype=np.float32)
+    X[3, 2] = np.nan
+    X[4, :] = np.inf
+    X[5, 0] = -np.inf
+    X[6, :] = 3.0e38
+    Q[0, :] = 0.0
+    Q[1, 1] = np.nan
+    Q[2, :] = np.abs(Q[2, :])
+    fmax = np.finfo(np.float32).max
+    for metric in (0, 1):
+        S = oracle.scores(X, Q, metric)                     # ranking scores (larger is better)
+        D, I = oracle.search(X, Q, k, metric)
+        qn = np.array([oracle.dot(q, q) for q in Q], dtype=np.float32)
+        for b in range(nq):
+            with np.errstate(invalid="ignore"):
+                admitted = [r for r in range(N) if S[b, r] > -fmax]          # NaN compares false
+            order = sorted(admitted, key=lambda r: (-S[b, r], r))[:k]
+            want_i = order + [-1] * (k - len(order))
+            np.testing.assert_array_equal(I[b], np.array(want_i))
+            for j, r in enumerate(order):
+                with np.errstate(invalid="ignore", over="ignore"):
+                    want = S[b, r] if metric == 0 else max(np.float32(0), np.float32(qn[b] - S[b, r]))
+                assert D[b, j] == want or (np.isnan(D[b, j]) and np.isnan(want))
+            assert (D[b, len(order):] == (-fmax if metric == 0 else fmax)).all()
+        assert (I[1] == -1).all() and 3 not in I

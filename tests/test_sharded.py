@@ -29,8 +29,13 @@ def _launch(mode, world, tmp_path, n, d, nq, k, metric):
             [sys.executable, os.path.join(HERE, "_sharded_worker.py"), mode, str(r), str(world), str(port), out,
              str(n), str(d), str(nq), str(k), str(metric)],
             env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    try:
+        for p in procs:
+            assert p.wait(timeout=300) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     return [np.load(o) for o in outs]
 
 
@@ -125,6 +130,33 @@ def test_concurrent_batches_on_the_serving_channel(tmp_path):
 def test_sharded_search_real_kernels_two_ranks_one_gpu(gpu_required, tmp_path, world, metric, k):
     n, d, nq = 40_003, 384, 32
     _check(_launch("gpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
+
+
+def _nccl_worlds():
+    """World sizes the RCCL test runs at: 1 always (the whole nccl code path on the one-GPU box), plus one
+    rank per GPU when the box has more (capped at 4: RCCL needs a GPU per rank, and the box allows few
+    processes on a card)."""
+    try:
+        import torch
+        n = torch.cuda.device_count()
+    except Exception:
+        n = 0
+    return [1] + ([min(n, 4)] if n > 1 else [])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", _nccl_worlds())
+@pytest.mark.parametrize("metric,k", [(0, 10), (1, 100)])
+def test_sharded_search_over_rccl(gpu_required, tmp_path, world, metric, k):
+    """BASELINE config D's collective leg: backend "nccl" — `all_gather_into_tensor` of the packed
+    per-shard results over RCCL, merged in place on the device, and the leader/follower protocol with its
+    control words on the device.  Ids and score bits equal the oracle's on every rank."""
+    n, d, nq = 60_007, 768, 32
+    results = _launch("nccl", world, tmp_path, n, d, nq, k, metric)
+    _check(results, n, d, nq, k, metric, world)
+    np.testing.assert_array_equal(results[0]["I3"], results[0]["I"])
+    np.testing.assert_array_equal(results[0]["D3"], results[0]["D"])
+    assert all(int(r["served"]) == 1 for r in results[1:])
 
 
 @pytest.mark.gpu
