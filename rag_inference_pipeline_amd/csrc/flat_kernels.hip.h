@@ -151,21 +151,33 @@ struct ScanParams {
     int n_tiles;           // ceil(n_rows / 32)
     int n_iters;           // rounds of the tile walk (the last one may be partial)
     int n_full;            // rounds in which every wave of every workgroup has a tile: n_tiles / (grid * NW)
-    const uint32_t* enable;  // null, or a device word: 0 turns the whole launch into a no-op (fallback path)
+    const uint32_t* enable;  // null, or a device word: unless it equals `epoch` the whole launch is a no-op (fallback path)
+    uint32_t epoch;          // id of the two-stage search this launch belongs to (never 0): per-search flags are
+                             // "set" when they hold it, so nothing has to be cleared between searches
     const u64* thr_key;      // null, or [kQT] keys (0 = none) whose score >= k rows are known to reach (sample pass):
                              // the filter starts there instead of at -inf
     int tile_step;           // tile t covers rows [32 t tile_step, +32): 1 for a full scan, > 1 for the sample pass
     // screening pass (P == 1) only
     int kout;              // keys emitted per (query, workgroup), >= k
-    const float* qscale;   // [kQT] power-of-two scale applied to a query before it is rounded to fp16
-    const float* unscale;  // [kQT] 1 / (qscale * corpus scale)
-    const float* margin;   // [kQT] width of the band kept below the running k-th best approximate score
-    uint32_t* lossy;       // [kQT] set when a workgroup could not hold a query's band (the certificate is void)
+    float x_absmax, x_normmax, x_scale;  // corpus statistics behind the error bound, and the corpus' fp16 scale
+    float* margin_out;     // [kQT] workgroup 0 publishes each query's band width for the resolve kernel
+    uint32_t* lossy;       // [kQT] = epoch when the certificate is void from the start (query outside the range the
+                           // bound covers) or a workgroup could not hold a query's band
+#ifdef RAGK_STAMPS
+    unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
+#endif
 };
 
+#ifdef RAGK_STAMPS
+#define RAGK_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RAGK_STAMP(i) do { } while (0)
+#endif
+
 // LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32][margin 32 f32]
+//             [query scale 32 f32][1 / (query scale * corpus scale) 32 f32]
 __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = columns held in LDS (one chunk)
-    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4;
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4 + 2 * kQT * 4;
 }
 
 // NW = waves per workgroup (NW/4 per SIMD), E = buffer capacity / 64, D = register ring depth
@@ -178,7 +190,8 @@ __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = colum
 //        running k-th best, which is what makes the exact second stage a proof rather than a guess.
 template <int NW, int E, int D, bool L2, int P>
 __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) {
-    if (p.enable && *p.enable == 0) return;  // launch-uniform
+    if (p.enable && *p.enable != p.epoch) return;  // launch-uniform
+    RAGK_STAMP(0);
     constexpr int C = 64 * E;
     constexpr int kScanWaves = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,6 +207,8 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     float* thr = reinterpret_cast<float*>(cnt + kQT);
     uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
     float* mrg = reinterpret_cast<float*>(flag + 4);
+    float* qsc_s = mrg + kQT;   // P == 1: per-query scales, computed in the prologue
+    float* uns_s = qsc_s + kQT;
 
     // ---- tile walk.  Rounds 0 .. n_full-1: wave w of workgroup b takes tile (b NW + w) + round * grid * NW
     // (the 8 waves of a workgroup read 8 consecutive tiles).  The last, partial round hands its leftover
@@ -216,122 +231,188 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         row = row < last_row ? row : last_row;
         return p.X + row * p.row_stride + p.col0 + 4 * h;
     };
-    // the first ring loads go out before the query image is built: their HBM latency runs under the prologue
+    // The first ring loads go out in the middle of the prologue — after the query loads, before their LDS
+    // stores.  Loads return in issue order: behind the ring's first touch of HBM (every CU at once) the
+    // query fragments, all L2 hits, would wait for it; ahead of it they are stored while it is in flight.
     int tile = tile_of(0);
     f32x4 xb[D];
     const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
+    auto issue_ring = [&]() {
 #pragma unroll
-    for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+        for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+    };
 
-    // ---- prologue: queries -> MFMA B fragments in LDS.  A thread's lane (hence its query row and column
-    // half) is the same in every trip, so its loads differ only in the step s: PU of them are issued back to
-    // back before the first LDS store (one trip at a time the twelve dependent L2 round trips of d = 768 were
-    // most of the kernel's fixed cost — every CU reads the same 96 KB at the same moment), and each
-    // workgroup starts at a different step so the 256 CUs do not all ask for the same lines at once.
-    {
-        constexpr int PU = 6;
-        constexpr int WPS = kScanWaves;             // steps covered per trip: one per wave
-        const int qrow = lane & 31, hh = lane >> 5;
-        const int rot = (int)((blockIdx.x * 5u) % (unsigned)S);
-        if (P == 1) {
-            // fragment (s, l) = Q[l&31][16s + 8(l>>5) .. +7] * qscale, as fp16
-            const float qsc = qrow < p.nq ? p.qscale[qrow] : 0.f;
-            const float* qbase = p.Q + (size_t)(qrow < p.nq ? qrow : 0) * p.d;
-            const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
-            for (int s0 = wave; s0 < S; s0 += WPS * PU) {
-                f32x4 va[PU], vb[PU];
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    int s = s0 + WPS * u;
-                    va[u] = vb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (s < S && qrow < p.nq) {
-                        s += rot;
-                        s = s >= S ? s - S : s;
-                        const int col = 16 * s + 8 * hh;
-                        if (q_vec && col + 7 < p.d) {
-                            va[u] = *reinterpret_cast<const f32x4*>(qbase + col);
-                            vb[u] = *reinterpret_cast<const f32x4*>(qbase + col + 4);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (col + j < p.d) va[u][j] = qbase[col + j];
-                                if (col + 4 + j < p.d) vb[u][j] = qbase[col + 4 + j];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    int s = s0 + WPS * u;
-                    if (s < S) {
-                        s += rot;
-                        s = s >= S ? s - S : s;
-                        f16x8 v;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = (_Float16)(va[u][j] * qsc);
-                            v[4 + j] = (_Float16)(vb[u][j] * qsc);
-                        }
-                        qf[s * 64 + lane] = __builtin_bit_cast(f32x4, v);
-                    }
-                }
-            }
-        } else {
-            // fragment (s, l) = Q[l&31][col0 + 8s + 4(l>>5) .. +3]
-            const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
-            const float* qbase = p.Q + (size_t)(qrow < p.nq ? qrow : 0) * p.d;
-            for (int s0 = wave; s0 < S; s0 += WPS * PU) {
-                f32x4 v[PU];
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    int s = s0 + WPS * u;
-                    v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (s < S && qrow < p.nq) {
-                        s += rot;
-                        s = s >= S ? s - S : s;
-                        const int col = p.col0 + 8 * s + 4 * hh;
-                        if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load per fragment
-                            v[u] = *reinterpret_cast<const f32x4*>(qbase + col);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (col + j < p.d) v[u][j] = qbase[col + j];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < PU; ++u) {
-                    int s = s0 + WPS * u;
-                    if (s < S) {
-                        s += rot;
-                        s = s >= S ? s - S : s;
-                        qf[s * 64 + lane] = v[u];
-                    }
-                }
-            }
-        }
-    }
-    if (tid < kQT) {
-        cnt[tid] = 0;
-        // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
-        // they never enter the slow path (left at -inf they tie forever and double the scan time)
-        float t0 = RAGK_SCORE_FLOOR;
-        if (p.thr_key && tid < p.nq && p.thr_key[tid] != 0ull) {
-            t0 = unord32((uint32_t)(p.thr_key[tid] >> 32));
-            if (P == 1) t0 -= p.margin[tid];  // the band below an approximate score that k rows reach
+    // per-query words of the filter state, requested first (wave 0)
+    float pre_t0 = RAGK_SCORE_FLOOR;
+    bool pre_seeded = false;
+    if (tid < kQT && tid < p.nq) {
+        if (p.thr_key) {
+            const u64 tk = p.thr_key[tid];
+            pre_seeded = tk != 0ull;
+            if (pre_seeded) pre_t0 = unord32((uint32_t)(tk >> 32));
         }
         // L2 with ||q||^2 = inf / NaN: every distance is inf or NaN, which faiss's heap never admits
         // (a NaN filter: `score >= NaN` is false for every score, +inf included)
-        if (L2 && tid < p.nq && !(p.qnorm[tid] <= 3.402823466e+38f)) t0 = __builtin_nanf("");
-        thr[tid] = tid < p.nq ? t0 : __builtin_inff();
-        if (P == 1) {
-            mrg[tid] = tid < p.nq ? p.margin[tid] : 0.f;
-            // a query the prep kernel ruled out (non-finite, out of range) is answered by the fallback
-            if (tid < p.nq && p.lossy[tid]) thr[tid] = __builtin_inff();
+        if (L2 && !(p.qnorm[tid] <= 3.402823466e+38f)) pre_t0 = __builtin_nanf("");
+    }
+
+    // ---- prologue: queries -> MFMA B fragments in LDS.  A thread's lane (hence its query row and column
+    // half) is the same in every trip, so its loads differ only in the step s: NF float4 loads are issued
+    // back to back before the first LDS store (one fragment at a time the twelve dependent L2 round trips
+    // of d = 768 were most of the kernel's fixed cost — every CU reads the same 96 KB at the same moment).
+    // P == 0: fragment (s, l) = Q[l&31][col0 + 8s + 4(l>>5) .. +3], one float4.
+    // P == 1: fragment (s, l) = Q[l&31][16s + 8(l>>5) .. +7] * qscale as fp16, two float4.
+    {
+        constexpr int FPS = P == 1 ? 2 : 1;         // float4 per fragment
+        constexpr int PU = 12 / FPS;                // fragments per trip: 48 VGPRs in flight (d <= 768: one trip)
+        constexpr int WPS = kScanWaves;             // steps covered per trip: one per wave
+        constexpr int CPS = P == 1 ? 16 : 8;        // columns per step
+        const int qrow = lane & 31, hh = lane >> 5;
+        const bool have_q = qrow < p.nq;
+        const float* qbase = p.Q + (size_t)(have_q ? qrow : 0) * p.d;
+        const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
+        f32x4 v[PU][FPS];
+        auto step_of = [&](int s0, int u) -> int {   // -1: past the end
+            const int s = s0 + WPS * u;
+            return s < S ? s : -1;
+        };
+        auto load_trip = [&](int s0) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int s = step_of(s0, u);
+#pragma unroll
+                for (int f = 0; f < FPS; ++f) {
+                    v[u][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (s >= 0 && have_q) {
+                        const int col = p.col0 + CPS * s + (CPS / 2) * hh + 4 * f;
+                        if (q_vec && col + 3 < p.d) {  // rows 16-byte aligned: one load
+                            v[u][f] = *reinterpret_cast<const f32x4*>(qbase + col);
+                        } else {
+                            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                            if (col + 0 < p.d) t[0] = qbase[col + 0];
+                            if (col + 1 < p.d) t[1] = qbase[col + 1];
+                            if (col + 2 < p.d) t[2] = qbase[col + 2];
+                            if (col + 3 < p.d) t[3] = qbase[col + 3];
+                            v[u][f] = t;
+                        }
+                    }
+                }
+            }
+        };
+        auto store_trip = [&](int s0, float qsc) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int s = step_of(s0, u);
+                if (s >= 0) {
+                    if constexpr (P == 1) {
+                        f16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            o[j] = (_Float16)(v[u][0][j] * qsc);
+                            o[4 + j] = (_Float16)(v[u][FPS - 1][j] * qsc);
+                        }
+                        qf[s * 64 + lane] = __builtin_bit_cast(f32x4, o);
+                    } else {
+                        qf[s * 64 + lane] = v[u][0];
+                    }
+                }
+            }
+        };
+        load_trip(wave);
+        issue_ring();
+        if constexpr (P == 1) {
+            // ---- what a separate prep launch used to do (4 us + a dependent-launch boundary): per query
+            // ||q||^2 and max |q_i| -> the power-of-two scale that puts the query high in the fp16 range,
+            // and the worst-case error bound eps of an approximate score (flat_kernels "two-stage exact
+            // search") -> margin = 2 eps.  Every workgroup derives them from the fragments it is loading
+            // anyway — same instructions, same order, same bits in every workgroup — and workgroup 0
+            // publishes the margins for the resolve kernel.  A thread holds its share of its query's row
+            // in registers; the 16 threads of a row meet through 4 KB of the (still empty) key buffers.
+            const bool one_trip = S <= WPS * PU;
+            float ss = 0.f, am = 0.f;
+            auto accumulate = [&]() {
+#pragma unroll
+                for (int u = 0; u < PU; ++u)
+#pragma unroll
+                    for (int f = 0; f < FPS; ++f)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = fabsf(v[u][f][j]);
+                            am = (a <= 3.0e38f) ? fmaxf(am, a) : __builtin_inff();  // NaN / inf poison the maximum
+                            ss = __builtin_fmaf(a, a, ss);
+                        }
+            };
+            accumulate();
+            for (int s0 = wave + WPS * PU; s0 < S; s0 += WPS * PU) {  // d > 768: the later trips are loaded twice
+                load_trip(s0);
+                accumulate();
+            }
+            float* part = reinterpret_cast<float*>(keys);
+            part[(qrow * 16 + wave * 2 + hh) * 2 + 0] = ss;
+            part[(qrow * 16 + wave * 2 + hh) * 2 + 1] = am;
+            __syncthreads();
+            if (tid < kQT) {
+                float tss = 0.f, tam = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    tss += part[(tid * 16 + i) * 2 + 0];
+                    tam = fmaxf(tam, part[(tid * 16 + i) * 2 + 1]);
+                }
+                float qscale = 0.f, unscale = 0.f, margin = 0.f;
+                bool parked = false;
+                if (tid < p.nq) {
+                    // usable range: the scales and their product must stay ordinary fp32 numbers
+                    const bool ok = tss <= 1.0e24f && (tam == 0.f || (tam >= 1.0e-12f && tam <= 1.0e12f));
+                    if (!ok) {
+                        parked = true;  // the fp32 fallback answers this query
+                        if (blockIdx.x == 0) p.lossy[tid] = p.epoch;
+                    } else {
+                        int e = 0;
+                        if (tam > 0.f) (void)frexpf(tam, &e);         // tam = m 2^e, m in [0.5, 1)
+                        qscale = ldexpf(1.f, 14 - e);                   // |q| qscale < 2^14
+                        unscale = 1.f / (qscale * p.x_scale);           // powers of two: exact
+                        const float d64f = (float)(2 * p.dc8);
+                        const float qn = sqrtf(tss) * 1.0001f;
+                        const float rel = 0.0009775f + 6.f * d64f * 5.9604645e-8f;  // 2^-10 (1 + 2^-11) rounded up; 6 d 2^-24
+                        const float eps = qn * p.x_normmax * rel +
+                                          sqrtf(d64f) * (qn * p.x_absmax + p.x_normmax * tam) * 7.4505806e-9f;  // 2^-27
+                        margin = 2.f * eps * 1.01f * (L2 ? 2.f : 1.f);
+                    }
+                    if (blockIdx.x == 0) p.margin_out[tid] = margin;
+                }
+                qsc_s[tid] = qscale;
+                uns_s[tid] = unscale;
+                mrg[tid] = margin;
+                cnt[tid] = 0;
+                // unused query columns (nq < 32) score 0 against every row: park their threshold at +inf so
+                // they never enter the slow path (left at -inf they tie forever and double the scan time)
+                float t0 = pre_t0;
+                if (pre_seeded) t0 -= margin;  // the band below an approximate score that k rows reach
+                thr[tid] = tid < p.nq ? (parked ? __builtin_inff() : t0) : __builtin_inff();
+            }
+            __syncthreads();  // scales visible; `part` (the key buffers) free again
+            const float qsc = qsc_s[qrow];
+            if (!one_trip) load_trip(wave);
+            store_trip(wave, qsc);
+            for (int s0 = wave + WPS * PU; s0 < S; s0 += WPS * PU) {
+                load_trip(s0);
+                store_trip(s0, qsc);
+            }
+        } else {
+            store_trip(wave, 0.f);
+            for (int s0 = wave + WPS * PU; s0 < S; s0 += WPS * PU) {
+                load_trip(s0);
+                store_trip(s0, 0.f);
+            }
+            if (tid < kQT) {
+                cnt[tid] = 0;
+                thr[tid] = tid < p.nq ? pre_t0 : __builtin_inff();  // unused columns parked (see above)
+            }
         }
     }
     if (tid < 4) flag[tid] = 0;
     __syncthreads();
+    RAGK_STAMP(1);
 
     const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
     // Warm start (k <= 16, 8-wave build, no sampled threshold): see the filter below.
@@ -422,7 +503,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         const long long row0 = (long long)tile * tile_rows;
         float sc[16];
         if (P == 1) {  // undo the power-of-two scales (exact)
-            const float uns = p.unscale[r];
+            const float uns = uns_s[r];
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] *= uns;
         }
@@ -558,7 +639,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                             if (keep > (uint32_t)(C - 16)) {  // the band does not fit: give it up for this query
                                 if (lane == 0) {
                                     mrg[q] = 0.f;
-                                    atomicOr(&p.lossy[q], 1u);
+                                    p.lossy[q] = p.epoch;
                                 }
                                 tnew = kscore;  // keep > C - 16 >= k implies full
                                 keep = (uint32_t)p.k;
@@ -607,9 +688,11 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                 pending = still;
             }
         }
+        if (it == 0) RAGK_STAMP(2);
     }
 
     if (p.acc_out) return;
+    RAGK_STAMP(3);
     // ---- epilogue: sort every buffer, emit k keys per query for this workgroup
     {
         constexpr int NQW = (kQT + kScanWaves - 1) / kScanWaves;
@@ -642,6 +725,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
             }
         }
     }
+    RAGK_STAMP(4);
 }
 
 // ---- sample pass -> starting thresholds ----------------------------------------------------------
@@ -706,7 +790,8 @@ struct MergeOut {
     long long id_offset;
     int metric;          // 0 IP, 1 L2
     int from_shards;     // keys carry (-distance, id) of already finished results
-    const uint32_t* qmask;  // null, or [nq] words: only queries with a non-zero word are written (fallback path)
+    const uint32_t* qmask;  // null, or [nq] words: only queries whose word equals `epoch` are written (fallback path)
+    uint32_t epoch;
 };
 
 // Wave-wide 64-bit max on the DPP cross-lane paths (quad permutes, row mirrors, row broadcasts): a
@@ -744,71 +829,110 @@ __host__ __device__ inline int merge_look(int n_lists, int list_len, int k) {
     return want < list_len ? want : list_len;
 }
 
-// OWN = lists per thread (n_lists <= 256 * OWN): a round is a serial chain of wave-wide instructions,
-// so every compare that a smaller OWN removes shortens all k rounds.
-template <class Src, int OWN>
-__global__ __launch_bounds__(256) void tournament_merge_kernel(const Src src, const int n_lists, const int k,
-                                                               const int look, const MergeOut out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* ahead = reinterpret_cast<u64*>(smem);  // [n_lists][look]
-    __shared__ u64 wmax[2][4];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    if (out.qmask && out.qmask[q] == 0) return;  // workgroup-uniform
-    for (int idx = tid; idx < n_lists * look; idx += 256) {
-        const int l = idx / look, p = idx - l * look;
-        ahead[idx] = src.get(q, l, p);
+// Staging of the look-ahead: NT threads, eight loads in flight each (one at a time, the six dependent
+// round trips of 256 lists x 6 keys were a third of the kernel).
+template <class Src, int NT>
+__device__ __forceinline__ void stage_heads(const Src& src, int q, int n_lists, int look, u64* ahead, int t) {
+    const int total = n_lists * look;
+    for (int base = 0; base < total; base += NT * 8) {
+        u64 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + t + NT * u;
+            const int l = idx / look;
+            v[u] = idx < total ? src.get(q, l, idx - l * look) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + t + NT * u;
+            if (idx < total) ahead[idx] = v[u];
+        }
     }
-    __syncthreads();
+}
+
+// The rounds.  WAVES x 64 threads take part, thread t owns lists t, t + 64 WAVES, ... (OWN of them:
+// n_lists <= 64 WAVES OWN).  A round is a serial chain — local max, wave-wide max, (WAVES > 1: four LDS
+// words and a barrier,) the winner advances — so everything a round does not need is kept out of it:
+// with up to 256 lists ONE wave plays (four lists per lane, no LDS, no barrier: 0.13 us per round against
+// 0.45 with four waves).  on_round(round, best key of the round) runs on every participating thread;
+// STOP_EMPTY ends the tournament when the lists run dry.  Returns the last round's key.
+template <class Src, int OWN, int WAVES, bool STOP_EMPTY, class OnRound>
+__device__ __forceinline__ u64 tournament_rounds(const Src& src, int q, int n_lists, int rounds, int list_len, int look,
+                                                 const u64* ahead, u64 (*wmax)[4], int t, OnRound on_round) {
+    constexpr int NT = 64 * WAVES;
     u64 head[OWN];
     int pos[OWN];
 #pragma unroll
     for (int j = 0; j < OWN; ++j) {
-        const int l = tid + 256 * j;
+        const int l = t + NT * j;
         pos[j] = 0;
-        head[j] = (l < n_lists && k > 0) ? ahead[(size_t)l * look] : 0ull;
+        head[j] = (l < n_lists && rounds > 0) ? ahead[(size_t)l * look] : 0ull;
     }
-    for (int round = 0; round < k; ++round) {
+    u64 bm = 0ull;
+    for (int round = 0; round < rounds; ++round) {
         u64 best = head[0];
 #pragma unroll
         for (int j = 1; j < OWN; ++j) best = umax64(best, head[j]);
         const u64 wm = wave_max_u64(best);
-        if ((tid & 63) == 0) wmax[round & 1][tid >> 6] = wm;
-        __syncthreads();  // the other parity is free again: its readers passed this barrier's predecessor
-        const u64 bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]),
-                              umax64(wmax[round & 1][2], wmax[round & 1][3]));
-        if (tid == 0) {
-            float s;
-            long long id;
-            if (bm == 0ull) {
-                s = out.metric ? 3.402823466e+38f : -3.402823466e+38f;
-                id = -1;
-            } else {
-                const float rs = unord32((uint32_t)(bm >> 32));
-                if (out.from_shards) {
-                    s = out.metric ? -rs : rs;
-                } else if (out.metric) {
-                    const float dist = out.qnorm[q] - rs;
-                    s = dist < 0.f ? 0.f : dist;
-                } else {
-                    s = rs;
-                }
-                id = (long long)(0xFFFFFFFFu - (uint32_t)(bm & 0xFFFFFFFFull)) + out.id_offset;
-            }
-            out.scores[(size_t)q * out.out_stride + round] = s;
-            out.ids[(size_t)q * out.out_stride + round] = id;
-            if (out.last_key && round == k - 1) out.last_key[q] = bm;
+        if constexpr (WAVES == 1) {
+            bm = wm;
+        } else {
+            if ((t & 63) == 0) wmax[round & 1][t >> 6] = wm;
+            __syncthreads();  // the other parity is free again: its readers passed this barrier's predecessor
+            bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]), umax64(wmax[round & 1][2], wmax[round & 1][3]));
         }
-        if (bm != 0ull && best == bm) {  // keys are unique, so exactly one thread advances one list
+        on_round(round, bm);
+        if (bm == 0ull) {
+            if (STOP_EMPTY) break;  // uniform over the participants
+            continue;
+        }
+        if (best == bm) {  // keys are unique, so exactly one thread advances one list
 #pragma unroll
             for (int j = 0; j < OWN; ++j) {
                 if (head[j] == bm) {
-                    const int l = tid + 256 * j;
+                    const int l = t + NT * j;
                     const int np = ++pos[j];
-                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < k ? src.get(q, l, np) : 0ull);
+                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < list_len ? src.get(q, l, np) : 0ull);
                 }
             }
         }
     }
+    return bm;
+}
+
+template <class Src, int OWN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void tournament_merge_kernel(const Src src, const int n_lists, const int k,
+                                                                      const int look, const MergeOut out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* ahead = reinterpret_cast<u64*>(smem);  // [n_lists][look]
+    __shared__ u64 wmax[2][4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    if (out.qmask && out.qmask[q] != out.epoch) return;  // workgroup-uniform
+    stage_heads<Src, 64 * WAVES>(src, q, n_lists, look, ahead, tid);
+    __syncthreads();
+    tournament_rounds<Src, OWN, WAVES, false>(src, q, n_lists, k, k, look, ahead, wmax, tid, [&](int round, u64 bm) {
+        if (tid != 0) return;
+        float s;
+        long long id;
+        if (bm == 0ull) {
+            s = out.metric ? 3.402823466e+38f : -3.402823466e+38f;
+            id = -1;
+        } else {
+            const float rs = unord32((uint32_t)(bm >> 32));
+            if (out.from_shards) {
+                s = out.metric ? -rs : rs;
+            } else if (out.metric) {
+                const float dist = out.qnorm[q] - rs;
+                s = dist < 0.f ? 0.f : dist;
+            } else {
+                s = rs;
+            }
+            id = (long long)(0xFFFFFFFFu - (uint32_t)(bm & 0xFFFFFFFFull)) + out.id_offset;
+        }
+        out.scores[(size_t)q * out.out_stride + round] = s;
+        out.ids[(size_t)q * out.out_stride + round] = id;
+        if (out.last_key && round == k - 1) out.last_key[q] = bm;
+    });
 }
 
 // ---- two-stage exact search: screening copy, certificate, exact second stage ---------------------
@@ -906,13 +1030,12 @@ __global__ __launch_bounds__(256) void screen_convert_kernel(const float* X, lon
     }
 }
 
-struct ScreenQueryState {   // per pass of <= 32 queries (device memory)
-    float qscale[kQT];
-    float unscale[kQT];
-    float margin[kQT];      // 2 eps (4 eps for L2 ranking scores)
+struct ScreenQueryState {   // per pass of <= 32 queries (device memory).  The flag words are EPOCH-valued: a flag
+                            // is set for the search whose epoch it holds, so no launch has to clear them.
+    float margin[kQT];      // 2 eps (4 eps for L2 ranking scores); written by workgroup 0 of the screening scan
     uint32_t lossy[kQT];    // certificate void: out-of-range query, or a workgroup dropped part of the band
     uint32_t sample_lossy[kQT];  // scratch for the sample pass (its lists only seed thresholds)
-    uint32_t fallback[kQT]; // set by the finalize kernel: this query goes through the fp32 scan
+    uint32_t fallback[kQT]; // set by the resolve kernel: this query goes through the fp32 scan
     uint32_t any_fallback;  // the fallback launches read this word
     uint32_t pad[3];
 };
@@ -923,64 +1046,6 @@ struct ScreenCounters {     // cumulative, read back by rag_index_screen_stats
     uint32_t max_err_ratio_bits;  // max observed |approx - exact| / eps over all verified candidates
     uint32_t pad;
 };
-
-// One workgroup per query: norms -> scales and margins; clears the per-pass flags.  d <= 2048, so a
-// thread reads at most eight elements and all of its loads are in flight together.
-__global__ __launch_bounds__(256) void screen_prep_kernel(const float* Q, int nq, int d, int d64, int l2, float x_absmax,
-                                                          float x_normmax, float x_scale, ScreenQueryState* qs) {
-    __shared__ float s_ss[4], s_am[4];
-    const int tid = threadIdx.x, q = blockIdx.x;  // grid = kQT: every slot of the state is rewritten
-    if (q == 0 && tid == 0) qs->any_fallback = 0;
-    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (q < nq) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + 256 * u;
-            if (c < d) v[u] = Q[(size_t)q * d + c];
-        }
-    }
-    float ss = 0.f, amax = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const float a = fabsf(v[u]);
-        amax = (a <= 3.0e38f) ? fmaxf(amax, a) : __builtin_inff();  // NaN / inf poison the maximum
-        ss = __builtin_fmaf(a, a, ss);
-    }
-    ss = wave_sum_f32(ss);
-    amax = wave_max_f32(amax);
-    if ((tid & 63) == 0) {
-        s_ss[tid >> 6] = ss;
-        s_am[tid >> 6] = amax;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    ss = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
-    amax = fmaxf(fmaxf(s_am[0], s_am[1]), fmaxf(s_am[2], s_am[3]));
-    float qscale = 1.f, unscale = 0.f, margin = 0.f;
-    uint32_t lossy = 0;
-    if (q < nq) {
-        // usable range: the scales and their product must stay ordinary fp32 numbers
-        const bool ok = ss <= 1.0e24f && (amax == 0.f || (amax >= 1.0e-12f && amax <= 1.0e12f));
-        if (!ok) {
-            lossy = 1;
-        } else {
-            int e = 0;
-            if (amax > 0.f) (void)frexpf(amax, &e);     // amax = m 2^e, m in [0.5, 1)
-            qscale = ldexpf(1.f, 14 - e);                 // |q| qscale < 2^14
-            unscale = 1.f / (qscale * x_scale);           // powers of two: exact
-            const float qn = sqrtf(ss) * 1.0001f;
-            const float rel = 0.0009775f + 6.f * (float)d64 * 5.9604645e-8f;  // 2^-10 (1 + 2^-11) rounded up; 6 d 2^-24
-            const float eps = qn * x_normmax * rel +
-                              sqrtf((float)d64) * (qn * x_absmax + x_normmax * amax) * 7.4505806e-9f;  // 2^-27
-            margin = 2.f * eps * 1.01f * (l2 ? 2.f : 1.f);
-        }
-    }
-    qs->qscale[q] = qscale;
-    qs->unscale[q] = unscale;
-    qs->margin[q] = margin;
-    qs->lossy[q] = lossy;
-    qs->fallback[q] = 0;
-}
 
 // Resolve: what turns the screening pass's lists into results — ONE launch, one 256-thread workgroup per
 // query (it was three: collect, verify, finalize, 27 us of kernels plus two dependent-launch boundaries
@@ -1007,6 +1072,7 @@ struct ResolveParams {
     const float* qnorm;      // canonical ||q||^2 (L2)
     long long id_offset;
     ScreenQueryState* qs;
+    uint32_t epoch;          // this search's id: the value "set" flags hold
     ScreenCounters* ctr;
     float* out_s;            // [nq][k]
     long long* out_i;
@@ -1019,7 +1085,7 @@ __host__ __device__ inline size_t resolve_lds_bytes(int d8, int n_lists, int loo
     return (size_t)kp * 16 + (size_t)d8 * sizeof(float) + (stage > ahead ? stage : ahead);
 }
 
-template <int OWN, int RPW>
+template <int OWN, int TW, int RPW>
 __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* c_keys = reinterpret_cast<u64*>(smem);                   // [kp] exact ranking keys
@@ -1029,14 +1095,12 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     u64* ahead = reinterpret_cast<u64*>(qv + p.d8);                 // [n_lists][look], phases A and B ...
     float* rows = reinterpret_cast<float*>(qv + p.d8);              // ... then [4 waves][RPW][d8 + 4], phase C
     __shared__ u64 wmax[2][4];
+    __shared__ u64 s_kth;
     __shared__ uint32_t s_cnt, s_cut;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_lists = p.n_lists, look = p.look, kp = p.kp, kout = p.src.k;
 
-    for (int idx = tid; idx < n_lists * look; idx += 256) {
-        const int l = idx / look, pp = idx - l * look;
-        ahead[idx] = p.src.get(q, l, pp);
-    }
+    stage_heads<KeyListSrc, 256>(p.src, q, n_lists, look, ahead, tid);
     for (int c = tid; c < p.d8; c += 256) qv[c] = c < p.d ? p.Q[(size_t)q * p.d + c] : 0.f;
     if (tid == 0) {
         s_cnt = 0;
@@ -1044,39 +1108,14 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     }
     __syncthreads();
 
-    // ---- (A) k-th best approximate key
-    u64 head[OWN];
-    int pos[OWN];
-#pragma unroll
-    for (int j = 0; j < OWN; ++j) {
-        const int l = tid + 256 * j;
-        pos[j] = 0;
-        head[j] = l < n_lists ? ahead[(size_t)l * look] : 0ull;
-    }
-    u64 kth = 0ull;
-    for (int round = 0; round < p.k; ++round) {
-        u64 best = head[0];
-#pragma unroll
-        for (int j = 1; j < OWN; ++j) best = umax64(best, head[j]);
-        const u64 wm = wave_max_u64(best);
-        if (lane == 0) wmax[round & 1][wave] = wm;
-        __syncthreads();
-        const u64 bm = umax64(umax64(wmax[round & 1][0], wmax[round & 1][1]),
-                              umax64(wmax[round & 1][2], wmax[round & 1][3]));
-        kth = bm;
-        if (bm == 0ull) break;  // fewer than k rows in all: everything listed is a candidate (workgroup-uniform)
-        if (best == bm) {
-#pragma unroll
-            for (int j = 0; j < OWN; ++j) {
-                if (head[j] == bm) {
-                    const int l = tid + 256 * j;
-                    const int np = ++pos[j];
-                    head[j] = np < look ? ahead[(size_t)l * look + np] : (np < kout ? p.src.get(q, l, np) : 0ull);
-                }
-            }
-        }
+    // ---- (A) k-th best approximate key (TW == 1: wave 0 alone plays the tournament)
+    if (TW == 4 || wave == 0) {
+        const u64 last = tournament_rounds<KeyListSrc, OWN, TW, true>(p.src, q, n_lists, p.k, kout, look, ahead, wmax, tid,
+                                                                       [](int, u64) {});
+        if (tid == 0) s_kth = last;  // 0: fewer than k rows in all, everything listed is a candidate
     }
     __syncthreads();
+    const u64 kth = s_kth;
 
     // ---- (B) the band
     const float margin = p.qs->margin[q];
@@ -1178,7 +1217,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     worst = wave_max_f32(worst);
     // the scan kept the whole band (not lossy), this kernel held it (no overflow), and — belt and braces —
     // no verified candidate shows an error beyond the bound the band was built from
-    bool ok = p.qs->lossy[q] == 0 && !overflow;
+    bool ok = p.qs->lossy[q] != p.epoch && !overflow;
     if (ok && !(worst <= eps)) ok = false;  // also catches eps == 0 with any error, and NaN
     if (n <= 64) {
         u64 k1[1][1] = {{kk[0][0]}};
@@ -1214,8 +1253,8 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     if (lane == 0) {
         atomicAdd(&p.ctr->queries, 1ull);
         if (!ok) {
-            p.qs->fallback[q] = 1;
-            atomicOr(&p.qs->any_fallback, 1u);
+            p.qs->fallback[q] = p.epoch;
+            p.qs->any_fallback = p.epoch;
             atomicAdd(&p.ctr->fallbacks, 1ull);
         } else if (eps > 0.f) {
             atomicMax(&p.ctr->max_err_ratio_bits, __float_as_uint(worst / eps));

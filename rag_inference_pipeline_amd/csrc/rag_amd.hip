@@ -142,6 +142,10 @@ int ensure_dyn_lds(const void* fn, size_t lds) {
     return RAG_OK;
 }
 
+#ifdef RAGK_STAMPS
+unsigned long long* g_stamps = nullptr;  // [2048][8], experiment build only
+#endif
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -194,6 +198,7 @@ struct rag_index {
     ragk::ScreenCorpusStats* sc_stats = nullptr;
     ragk::ScreenQueryState* sq = nullptr;
     ragk::ScreenCounters* sctr = nullptr;
+    uint32_t screen_epoch = 0;   // id of the last two-stage search (ragk::ScreenQueryState flags are epoch-valued)
 
     // sample pass (starting thresholds for k >= kSampleMinK)
     ragk::u64* sample_heads = nullptr;  // kQT x kSampleLists workgroup maxima
@@ -305,12 +310,12 @@ template <class Src>
 void launch_merge(const Src& src, int n_lists, int nq, int k, int look, const ragk::MergeOut& mo, hipStream_t st) {
     using namespace ragk;
     const size_t lds = (size_t)n_lists * look * 8;
-    if (n_lists <= 256)
-        tournament_merge_kernel<Src, 1><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+    if (n_lists <= 256)  // one wave, four lists per lane: no barrier inside a round
+        tournament_merge_kernel<Src, 4, 1><<<dim3(nq), dim3(64), lds, st>>>(src, n_lists, k, look, mo);
     else if (n_lists <= 512)
-        tournament_merge_kernel<Src, 2><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+        tournament_merge_kernel<Src, 2, 4><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
     else
-        tournament_merge_kernel<Src, kMergeMaxOwned><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
+        tournament_merge_kernel<Src, kMergeMaxOwned, 4><<<dim3(nq), dim3(256), lds, st>>>(src, n_lists, k, look, mo);
 }
 
 void prof_push(rag_index* h, hipEvent_t e0, hipEvent_t e1) {
@@ -370,6 +375,9 @@ int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_
     ss.tile_step = (int)(base.n_tiles / ss.n_tiles);
     ss.thr_key = nullptr;
     ss.enable = nullptr;
+#ifdef RAGK_STAMPS
+    ss.stamps = nullptr;
+#endif
     if (ss.lossy) ss.lossy = h->sq->sample_lossy;
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipLaunchKernelGGL(fn, dim3(lists), dim3(8 * 64), lds, st, ss);
@@ -386,7 +394,7 @@ int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_
 // *enable == 0 every launch returns at once, otherwise only queries with qmask[q] != 0 are written.
 int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u64* ceil, ragk::u64* last_key,
                  float* out_s, long long* out_i, int out_stride, hipStream_t st, const uint32_t* enable = nullptr,
-                 const uint32_t* qmask = nullptr) {
+                 const uint32_t* qmask = nullptr, uint32_t epoch = 0) {
     using namespace ragk;
     const int dc_full = chunk_cols(h->d8);
     const int cap = pick_capacity(dc_full, k);
@@ -440,11 +448,17 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.n_iters = n_iters;
         sp.n_full = n_tiles / (grid * waves);
         sp.enable = enable;
+        sp.epoch = epoch;
         sp.thr_key = sampled ? h->thr_keys : nullptr;
         sp.tile_step = 1;
         sp.kout = k;
-        sp.qscale = sp.unscale = sp.margin = nullptr;
+        sp.x_absmax = sp.x_normmax = sp.x_scale = 0.f;
+        sp.margin_out = nullptr;
         sp.lossy = nullptr;
+#ifdef RAGK_STAMPS
+        if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
+        sp.stamps = enable ? nullptr : g_stamps;
+#endif
         return sp;
     };
     if (sampled) {
@@ -487,7 +501,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
     // merge: per query the top-k of the grid sorted lists, decoded into (score, id)
     if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
     KeyListSrc src{h->partial, grid, k};
-    MergeOut mo{out_s, out_i, last_key, out_stride, h->qnorm, h->id_offset, h->metric, 0, qmask};
+    MergeOut mo{out_s, out_i, last_key, out_stride, h->qnorm, h->id_offset, h->metric, 0, qmask, epoch};
     const int look = merge_look(grid, k, k);
     launch_merge(src, grid, nq, k, look, mo, st);
     HIP_TRY(hipGetLastError());
@@ -497,10 +511,10 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
 // Exact search of one block of <= 32 queries, any k: rounds of kmax when k exceeds what one fused pass
 // can select (LDS budget), each round a full scan restricted to keys below the previous round's last key.
 int search_exact_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st,
-                       const uint32_t* enable = nullptr, const uint32_t* qmask = nullptr) {
+                       const uint32_t* enable = nullptr, const uint32_t* qmask = nullptr, uint32_t epoch = 0) {
     const int kmax = rag_index_max_k(h->d, nb);
     if (kmax <= 0) return fail(RAG_ERR_UNSUPPORTED, "dimension %d is not supported by the scan kernel", h->d);
-    if (k <= kmax) return search_round(h, qp, nb, k, nullptr, nullptr, os, oi, k, st, enable, qmask);
+    if (k <= kmax) return search_round(h, qp, nb, k, nullptr, nullptr, os, oi, k, st, enable, qmask, epoch);
     if (!h->round_keys) {
         int rc = dev_alloc(&h->round_keys, (size_t)2 * ragk::kQT);
         if (rc) return rc;
@@ -510,7 +524,7 @@ int search_exact_block(rag_index* h, const float* qp, int nb, int k, float* os, 
         const int kr = std::min(kmax, k - done);
         const ragk::u64* ceil = done ? h->round_keys + (size_t)flip * ragk::kQT : nullptr;
         ragk::u64* last = h->round_keys + (size_t)(flip ^ 1) * ragk::kQT;
-        int rc = search_round(h, qp, nb, kr, ceil, last, os + done, oi + done, k, st, enable, qmask);
+        int rc = search_round(h, qp, nb, kr, ceil, last, os + done, oi + done, k, st, enable, qmask, epoch);
         if (rc) return rc;
         done += kr;
         flip ^= 1;
@@ -557,9 +571,9 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(qp, h->d, h->d, 0, nb, h->qnorm);
         HIP_TRY(hipGetLastError());
     }
-    screen_prep_kernel<<<dim3(kQT), dim3(256), 0, st>>>(qp, nb, h->d, h->d64, l2 ? 1 : 0, h->x_absmax, h->x_normmax,
-                                                           h->x_scale, h->sq);
-    HIP_TRY(hipGetLastError());
+    // one id per two-stage search: the per-search flag words are "set" when they hold it (never 0)
+    if (++h->screen_epoch == 0) h->screen_epoch = 1;
+    const uint32_t epoch = h->screen_epoch;
 
     // stage 1: screening scan over the fp16 copy (addresses in 4-byte units: 16 halves = 8 units per step)
     const bool sampled = k >= kSampleMinK && n_tiles_ll >= kSampleMinTiles;
@@ -585,16 +599,22 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.n_iters = n_iters;
     sp.n_full = n_tiles / (grid * waves);
     sp.enable = nullptr;
+    sp.epoch = epoch;
     sp.thr_key = nullptr;
     sp.tile_step = 1;
     // keys a workgroup emits per query: its LDS buffer never holds more than `cap`, so longer lists would
     // be zero padding (at kp = 240 that was 15.7 MB of zeros written per batch and left dirty in L2)
     const int kout = std::min(kp, cap);
     sp.kout = kout;
-    sp.qscale = h->sq->qscale;
-    sp.unscale = h->sq->unscale;
-    sp.margin = h->sq->margin;
+    sp.x_absmax = h->x_absmax;
+    sp.x_normmax = h->x_normmax;
+    sp.x_scale = h->x_scale;
+    sp.margin_out = h->sq->margin;
     sp.lossy = h->sq->lossy;
+#ifdef RAGK_STAMPS
+    if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
+    sp.stamps = g_stamps;
+#endif
     const int S = h->d64 / 16;
     if (sampled) {
         rc = run_sample_pass(h, sp, screen_fn(64, S % 8 == 0 ? 8 : 4, l2), scan_lds_bytes(h->d64 / 2, 64), nb, k, st);
@@ -639,6 +659,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         rp.qnorm = h->qnorm;
         rp.id_offset = h->id_offset;
         rp.qs = h->sq;
+        rp.epoch = epoch;
         rp.ctr = h->sctr;
         rp.out_s = os;
         rp.out_i = oi;
@@ -646,18 +667,18 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         using ResolveFn = void (*)(const ResolveParams);
         ResolveFn resolve;
         if (h->d8 <= 1024)
-            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<1, 8>
-                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 8> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 8>);
+            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<4, 1, 8>
+                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 4, 8> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 4, 8>);
         else
-            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<1, 4>
-                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 4> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 4>);
+            resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<4, 1, 4>
+                                  : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 4, 4> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 4, 4>);
         if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(resolve), rlds))) return rc;
         hipLaunchKernelGGL(resolve, dim3(nb), dim3(256), rlds, st, rp);
         HIP_TRY(hipGetLastError());
     }
 
     // fallback: the fp32 search of this block, enqueued unconditionally, a no-op unless a certificate failed
-    return search_exact_block(h, qp, nb, k, os, oi, st, &h->sq->any_fallback, h->sq->fallback);
+    return search_exact_block(h, qp, nb, k, os, oi, st, &h->sq->any_fallback, h->sq->fallback, epoch);
 }
 
 int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i,
@@ -1081,7 +1102,7 @@ int merge_shards(int device, int metric, int n_shards, int nq, int k, const floa
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
     ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
-    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr};
+    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr, 0};
     const int look = merge_look(n_shards, k, k);
     launch_merge(src, n_shards, nq, k, look, mo, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1108,3 +1129,13 @@ extern "C" int rag_merge_topk_packed_device(int32_t device, int32_t metric, int3
                         shard_stride_bytes / 4, reinterpret_cast<const long long*>(base), shard_stride_bytes / 8,
                         out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), stream);
 }
+
+#ifdef RAGK_STAMPS
+// experiment build: phase stamps of the last stamped scan launch, [n_wg][8] (device-synchronising)
+extern "C" int rag_debug_scan_stamps(unsigned long long* out, int32_t n_wg) {
+    if (!g_stamps || !out || n_wg <= 0 || n_wg > 2048) return RAG_ERR_INVALID_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return RAG_ERR_HIP;
+    if (hipMemcpy(out, g_stamps, (size_t)n_wg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return RAG_ERR_HIP;
+    return RAG_OK;
+}
+#endif
