@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
+TRAFFIC_FILE = "r02_scan_hbm_traffic.json"  # PMC pass of this workload (profiles/README.md says how it was collected)
 
 # xor of the returned ids for the default workload (rows, dim, batch, k, seed), as produced by the
 # 1-GPU run that the full-size parity test checks against the oracle; sharded runs must reproduce it
@@ -52,9 +53,34 @@ def parse_args() -> argparse.Namespace:
     return ap.parse_args()
 
 
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_cpu(fn, budget_s: float, max_reps: int) -> tuple[int, float]:
+    fn()  # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= max_reps:
+            return reps, el
+
+
 def cpu_baseline(args: argparse.Namespace) -> dict:
-    """The oracle (a C/OpenMP port of the IndexFlat algorithm) timed on this box's host cores on a
-    bounded sample of the same workload; queries/sec scaled linearly to the full corpus."""
+    """The CPU path timed on this box's host cores on a bounded sample of the same workload; queries/sec
+    scaled linearly to the full corpus.  `import faiss` is PROBED: when it imports, the real
+    IndexFlatIP.search is the baseline (`kind: "reference"`) and the oracle's figure rides along; when it
+    does not, the baseline is the oracle — a C/OpenMP port of the IndexFlat algorithm (`kind: "port"`) —
+    and the line says why."""
     from oracle import flat as oracle
 
     n = min(args.cpu_sample_rows, args.rows)
@@ -64,25 +90,39 @@ def cpu_baseline(args: argparse.Namespace) -> dict:
     cores = max(1, min(16, avail, oracle.num_threads()))
     X = oracle.synth_rows(args.seed, 0, n, args.dim)
     Q = oracle.synth_rows(args.seed + 3087, 0, args.batch, args.dim)
-    oracle.search(X, Q, args.k, nthreads=cores)  # warm
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.search(X, Q, args.k, nthreads=cores)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 20:
-            break
-    qps_sample = args.batch * reps / el
     scale = n / float(args.rows)
-    return {
-        "value": qps_sample * scale,
+    reps, el = _time_cpu(lambda: oracle.search(X, Q, args.k, nthreads=cores), 8.0, 20)
+    port = {"value": args.batch * reps / el * scale, "cores": cores, "ms_per_batch_on_sample": el / reps * 1e3}
+    out = {
+        "value": port["value"],
         "unit": "queries/s",
         "cores": cores,
         "kind": "port",
+        "cpu_model": _cpu_model(),
+        "logical_cpus_visible": avail,
         "sample": f"oracle/flat_oracle.c (AVX2+FMA, OpenMP x{cores}) on the first {n} of {args.rows} rows, "
                   f"{reps} batches of {args.batch} at {el / reps * 1e3:.1f} ms/batch; "
                   f"queries/s scaled x{scale:g} (scan cost is linear in rows)",
     }
+    all_threads = min(avail, oracle.num_threads())
+    if all_threads > cores:  # every core the process may use, next to the reference's 16-thread policy
+        r2, e2 = _time_cpu(lambda: oracle.search(X, Q, args.k, nthreads=all_threads), 6.0, 20)
+        out["all_cores"] = {"value": args.batch * r2 / e2 * scale, "unit": "queries/s", "cores": all_threads,
+                            "ms_per_batch_on_sample": e2 / r2 * 1e3}
+    try:
+        import faiss  # noqa: F401  (probe: the GPU box receives only this repo, faiss may or may not be there)
+    except Exception as exc:  # noqa: BLE001
+        out["faiss"] = f"not importable on this box ({type(exc).__name__}): baseline is the port"
+    else:
+        faiss.omp_set_num_threads(cores)  # reference runtime.py:76
+        fidx = faiss.IndexFlatIP(args.dim)
+        fidx.add(X)
+        r3, e3 = _time_cpu(lambda: fidx.search(Q, args.k), 8.0, 20)
+        out.update({"value": args.batch * r3 / e3 * scale, "kind": "reference",
+                    "sample": f"faiss {faiss.__version__} IndexFlatIP.search, {cores} OpenMP threads, on the first {n} of "
+                              f"{args.rows} rows, {r3} batches at {e3 / r3 * 1e3:.1f} ms/batch; scaled x{scale:g}",
+                    "port": port, "faiss": faiss.__version__})
+    return out
 
 
 def main() -> None:
@@ -174,6 +214,30 @@ def main() -> None:
     res_s = (fin["s"] if world > 1 else out_s).cpu().numpy()
     res_i = (fin["i"] if world > 1 else out_i).cpu().numpy()
 
+    # SURVEY 8(d) timing protocol, literally: host submit -> results on host.  One batch of host-resident
+    # queries through rag_index_search (pinned staging, H2D of B*d*4 bytes, scan + merge, D2H of 12*B*k bytes,
+    # stream sync) per step; p50 over the steps.  PCIe-inclusive, so never `value`.
+    def host_leg() -> dict | None:
+        if world > 1:
+            return None
+        Qh = np.ascontiguousarray(Q.cpu().numpy())
+        for _ in range(max(2, args.warmup)):
+            index.search(Qh, k)
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t1 = time.perf_counter()
+            Dh, Ih = index.search(Qh, k)
+            per.append(time.perf_counter() - t1)
+        el = time.perf_counter() - t0
+        return {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                "p50_latency_ms": float(np.median(per) * 1e3), "p95_latency_ms": float(np.percentile(per, 95) * 1e3),
+                "steps": args.steps,
+                "identical_to_device_path": bool(np.array_equal(Ih, res_i) and np.array_equal(Dh.view(np.uint32), res_s.view(np.uint32))),
+                "path": f"rag_index_search: host queries ({B * d * 4} B H2D) -> results on host ({12 * B * k} B D2H), one sync per batch"}
+
+    host_one_pass = host_leg()
+
     # Extra leg (reported beside the headline, never as `value`): the same step with the query encoder
     # in front — token ids resident in HBM -> bge-base-architecture encoder (fp32 MFMA, seeded random
     # weights: no checkpoint exists offline) -> CLS pooling + L2 norm -> scan + top-k.  Every rank
@@ -253,6 +317,7 @@ def main() -> None:
                 torch.cuda.synchronize()
                 lat2.append(time.perf_counter() - t1)
             st = index.screen_stats()
+            host_two_stage = host_leg()
             enc2 = None
             if enc_step is not None:  # text ids -> encoder -> two-stage search
                 for _ in range(2):
@@ -291,6 +356,8 @@ def main() -> None:
             }
             if enc2 is not None:
                 two_leg["with_query_encoder"] = enc2
+            if host_two_stage is not None:
+                two_leg["host_submit_to_host_results"] = host_two_stage
 
     if model is not None:
         model.close()
@@ -301,7 +368,7 @@ def main() -> None:
         # guide prescribes); only quoted when it was collected on this exact workload
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_scan_hbm_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as fh:
                 tr = json.load(fh)
             w = tr["workload"]
             if (w["rows"], w["dim"], w["batch"], w["k"], w["n_gpus"]) == (N, d, B, k, world):
@@ -331,9 +398,11 @@ def main() -> None:
                             f"({n_local} rows on rank 0), batch {B} precomputed unit-norm query embeddings "
                             "resident in HBM (configs/retrieval_faiss_only.yaml path)"
                             + ("; per-shard top-k merged by one RCCL all-gather + device merge" if world > 1 else ""),
-                "note": "value = the one-pass fp32 scan (the path SURVEY 8(d) defines the roofline on); "
-                        "two_stage_exact = the same step through the optional exact two-stage search "
-                        "(same ids and score bits), reported beside it",
+                "note": "value = the one-pass fp32 scan with queries resident in HBM (the path SURVEY 8(d) defines the "
+                        "roofline on); host_submit_to_host_results = the same batches through rag_index_search "
+                        "(host queries in, results on host, PCIe inclusive) with its own q/s and p50; "
+                        "two_stage_exact = the same step through the exact two-stage search FAISSStore uses by "
+                        "default (same ids and score bits), reported beside it",
                 "rows": N, "dim": d, "batch": B, "k": k, "rows_per_gpu": n_local,
                 "parallelism": f"corpus-shard x{world}",
             },
@@ -346,6 +415,8 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "traffic_source": (f"profiles/{TRAFFIC_FILE}: FETCH_SIZE x2 (gfx950 correction) from a separate rocprofv3 --pmc "
+                                   "pass of this workload; not collected inside this run") if traffic is not None else None,
                 "avg_kernel_ms": scan_ms,
                 "launches": scan_launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -354,6 +425,8 @@ def main() -> None:
             "result_checksum_expected": EXPECTED_ID_CHECKSUM.get((N, d, B, k, args.seed)),
             "top1_score_mean": float(res_s[:, 0].mean()),
         }
+        if host_one_pass is not None:
+            out["host_submit_to_host_results"] = host_one_pass
         if enc_leg is not None:
             out["with_query_encoder"] = enc_leg
         if two_leg is not None:
