@@ -5,6 +5,8 @@ import os
 import textwrap
 import time
 
+import importlib.util
+
 import numpy as np
 import pytest
 
@@ -325,6 +327,76 @@ def test_executor_compressed_payload_mode_is_an_lz4_frame_of_compact_json():
     assert [d["doc_id"] for d in docs] == [2, 1, 0] and docs[0]["score"] == pytest.approx(1 / 3)
 
 
+def _liblz4_decompress(frame: bytes) -> bytes:
+    """Independent reader for the `compressed` payload: the system's liblz4 (the library behind python-lz4,
+    which the generation node decodes with: generation/service.py:429-431), through ctypes LZ4F_decompress.
+    Tests only — the product never links it."""
+    import ctypes as C
+    import ctypes.util
+
+    path = ctypes.util.find_library("lz4") or "liblz4.so.1"
+    try:
+        lib = C.CDLL(path)
+    except OSError:
+        pytest.skip("liblz4 is not installed on this machine")
+    lib.LZ4F_getVersion.restype = C.c_uint
+    lib.LZ4F_createDecompressionContext.restype = C.c_size_t
+    lib.LZ4F_createDecompressionContext.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    lib.LZ4F_freeDecompressionContext.argtypes = [C.c_void_p]
+    lib.LZ4F_isError.restype = C.c_uint
+    lib.LZ4F_isError.argtypes = [C.c_size_t]
+    lib.LZ4F_getErrorName.restype = C.c_char_p
+    lib.LZ4F_getErrorName.argtypes = [C.c_size_t]
+    lib.LZ4F_decompress.restype = C.c_size_t
+    lib.LZ4F_decompress.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p]
+    ctx = C.c_void_p()
+    rc = lib.LZ4F_createDecompressionContext(C.byref(ctx), lib.LZ4F_getVersion())
+    assert not lib.LZ4F_isError(rc), lib.LZ4F_getErrorName(rc)
+    out = bytearray()
+    try:
+        src = C.create_string_buffer(frame, len(frame))
+        dst = C.create_string_buffer(1 << 20)
+        pos, hint = 0, 1
+        while pos < len(frame):
+            dn, sn = C.c_size_t(len(dst)), C.c_size_t(len(frame) - pos)
+            hint = lib.LZ4F_decompress(ctx, dst, C.byref(dn), C.byref(src, pos), C.byref(sn), None)
+            assert not lib.LZ4F_isError(hint), lib.LZ4F_getErrorName(hint)
+            out += dst.raw[:dn.value]
+            pos += sn.value
+            assert sn.value or dn.value, "liblz4 made no progress"
+        assert hint == 0, "liblz4: frame not complete at the end of the input"
+    finally:
+        lib.LZ4F_freeDecompressionContext(ctx)
+    return bytes(out)
+
+
+def test_compressed_payload_decodes_through_liblz4():
+    """frames from lz4frame.compress (csrc/rag_lz4.cpp block compressor + frame header)
+    were only ever read back by this repo's own decoder.  Here the system's liblz4 — an implementation
+    that shares no code with this repo — decodes the retrieval node's `compressed` payload, the edge
+    cases of the frame test and the whole fuzz corpus of test_lz4_frame_fuzz_round_trip."""
+    import json
+    import os
+
+    from rag_inference_pipeline_amd import lz4frame
+    ex, _ = _executor({"faiss_store": _Index(), "embedding_generator": _Embedder(), "reranker": _Reranker()},
+                      DOCUMENTS_PAYLOAD_MODE="compressed")
+    for it in ex._process_batch_sync(Batch(1, [_req(0), _req(1)])):
+        raw = _liblz4_decompress(it.compressed_docs)
+        assert raw == lz4frame.decompress(it.compressed_docs) and len(json.loads(raw)) == 3
+    rng = np.random.default_rng(0)
+    words = [b"retrieval", b"augmented", b"generation", b"pipeline", b"vector", b"index", b" ", b"\xc3\xa9"]
+    for data in [b"", b"a", b"abc" * 5, bytes(70_000), os.urandom(3000), b"".join(rng.choice(words, size=20_000)),
+                 bytes(range(256)) * 40, b"x" * ((4 << 20) + 17)]:
+        assert _liblz4_decompress(lz4frame.compress(data)) == data
+    for trial, data in enumerate(_lz4_fuzz_corpus()):
+        assert _liblz4_decompress(lz4frame.compress(data)) == data, trial
+    if importlib.util.find_spec("lz4") is not None:      # python-lz4 itself, when a machine has it
+        import lz4.frame
+        for data in list(_lz4_fuzz_corpus())[:50]:
+            assert lz4.frame.decompress(lz4frame.compress(data)) == data
+
+
 def test_lz4_frame_round_trips_and_header_checksum():
     import os
 
@@ -341,12 +413,11 @@ def test_lz4_frame_round_trips_and_header_checksum():
     assert len(lz4frame.compress(text)) < len(text) // 2    # it does compress
 
 
-def test_lz4_frame_fuzz_round_trip():
+def _lz4_fuzz_corpus():
     """300 seeded buffers mixing literals, short and long matches, overlapping copies and block
-    boundaries of the token format (lengths around 15 / 270, offsets up to 65535)."""
-    from rag_inference_pipeline_amd import lz4frame
+    boundaries of the token format (lengths around 15 / 270, offsets up to 65535), plus a match beyond the window."""
     rng = np.random.default_rng(7)
-    for trial in range(300):
+    for _ in range(300):
         parts = []
         for _ in range(int(rng.integers(1, 12))):
             kind = int(rng.integers(0, 4))
@@ -359,11 +430,15 @@ def test_lz4_frame_fuzz_round_trip():
                 parts.append(unit * int(rng.integers(1, 60)))
             elif parts:
                 parts.append(parts[int(rng.integers(0, len(parts)))])          # a far back-reference
-        data = b"".join(parts)
-        assert lz4frame.decompress(lz4frame.compress(data)) == data, trial
+        yield b"".join(parts)
     far = np.random.default_rng(8).integers(0, 256, size=300, dtype=np.uint8).tobytes()
-    data = far + bytes(70_000) + far                       # the second copy is beyond the 64 KiB window
-    assert lz4frame.decompress(lz4frame.compress(data)) == data
+    yield far + bytes(70_000) + far                        # the second copy is beyond the 64 KiB window
+
+
+def test_lz4_frame_fuzz_round_trip():
+    from rag_inference_pipeline_amd import lz4frame
+    for trial, data in enumerate(_lz4_fuzz_corpus()):
+        assert lz4frame.decompress(lz4frame.compress(data)) == data, trial
 
 
 def test_executor_result_cache_hits_skip_the_index():
