@@ -325,6 +325,13 @@ class BertModel:
         kind = _native.BERT_OUT_PROBS if sigmoid else _native.BERT_OUT_LOGITS
         return self._forward(ids, types, cu, kind, False, (len(seqs), self.cfg.n_labels))
 
+    def classify_packed(self, ids: np.ndarray, types: np.ndarray | None, cu: np.ndarray, sigmoid: bool = True
+                        ) -> np.ndarray:
+        """classify() on sequences that are already packed (pack_sequences): the caller packed them on
+        another thread while the previous pass was running."""
+        kind = _native.BERT_OUT_PROBS if sigmoid else _native.BERT_OUT_LOGITS
+        return self._forward(ids, types, cu, kind, False, (len(cu) - 1, self.cfg.n_labels))
+
     def hidden_states(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None
                       ) -> np.ndarray:
         ids, types, cu = pack_sequences(seqs, type_seqs)

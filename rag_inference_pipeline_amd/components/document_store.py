@@ -59,34 +59,47 @@ class DocumentStore:
                 self._conns.append(conn)
         return conn
 
+    _MAX_VARS = 900  # stay under SQLite's bound-variable limit (999 in old builds)
+
+    def _fetch_map(self, wanted: list[int], truncate_length: int | None) -> dict[int, Document]:
+        """{doc_id: Document} of the ids that exist, already truncated; one IN (...) query per 900 ids."""
+        found: dict[int, Document] = {}
+        cur = self._connection().cursor()
+        cur.row_factory = None  # plain tuples: no sqlite3.Row per document
+        cut = truncate_length
+        try:
+            for lo in range(0, len(wanted), self._MAX_VARS):
+                part = wanted[lo:lo + self._MAX_VARS]
+                marks = ",".join("?" * len(part))
+                for doc_id, title, content, category in cur.execute(
+                        f"SELECT doc_id, title, content, category FROM documents WHERE doc_id IN ({marks})", part):
+                    title, content = title or "", content or ""
+                    if cut is not None:
+                        title, content = title[:cut], content[:cut]
+                    found[doc_id] = Document(doc_id, title, content, category or None)
+        except sqlite3.Error as exc:
+            logger.exception("SQLite error fetching documents")
+            raise RuntimeError(f"Failed to fetch documents: {exc}") from exc
+        finally:
+            cur.close()
+        return found
+
     def fetch_documents(self, doc_ids: list[int]) -> list[Document]:
         if not doc_ids:
             return []
         wanted = [int(i) for i in doc_ids]
-        found: dict[int, Document] = {}
-        conn = self._connection()
-        try:
-            for lo in range(0, len(wanted), 500):  # stay under SQLite's bound-variable limit
-                part = wanted[lo:lo + 500]
-                marks = ",".join("?" * len(part))
-                for row in conn.execute(
-                        f"SELECT doc_id, title, content, category FROM documents WHERE doc_id IN ({marks})", part):
-                    found[row["doc_id"]] = Document(row["doc_id"], row["title"] or "", row["content"] or "",
-                                                    row["category"] or None)
-        except sqlite3.Error as exc:
-            logger.exception("SQLite error fetching documents")
-            raise RuntimeError(f"Failed to fetch documents: {exc}") from exc
+        found = self._fetch_map(wanted, None)
         return [found[i] for i in wanted if i in found]
 
     def fetch_documents_batch(self, doc_ids_batch: list[list[int]],
                               truncate_length: int | None = None) -> list[list[Document]]:
-        out: list[list[Document]] = []
-        for doc_ids in doc_ids_batch:
-            docs = self.fetch_documents(doc_ids)
-            if truncate_length is not None:
-                docs = [d.truncate(truncate_length) for d in docs]
-            out.append(docs)
-        return out
+        """Documents of a whole batch, per query in the requested order, unknown ids dropped (reference
+        :278-302 fans a thread pool of per-query fetches out; here the batch's distinct ids go through ONE
+        pass over the table — 3200 ids at top-100 — and the per-query lists are cut from the result)."""
+        lists = [[int(i) for i in ids] for ids in doc_ids_batch]
+        distinct = list(dict.fromkeys(i for ids in lists for i in ids))
+        found = self._fetch_map(distinct, truncate_length) if distinct else {}
+        return [[found[i] for i in ids if i in found] for ids in lists]
 
     def close_all(self) -> None:
         with self._lock:

@@ -25,14 +25,16 @@ import logging
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-from ..bert import iter_token_budget
+from ..bert import iter_token_budget, pack_sequences
 from ..config import PipelineSettings, resolve_gpu_device
-from .schemas import Document, RerankedDocument
+from .schemas import Document, RerankedDocument, fast_constructor
 
 logger = logging.getLogger(__name__)
 
 _MAX_TOKENS_PER_PASS = 131072
 _PAIRS_PER_CHUNK = 640   # ~35 k tokens at the synthetic corpus' lengths: still the big-batch GEMM path
+_FIRST_CHUNK = 160       # the first chunk's tokenisation is the only one the GPU waits for: keep it short
+_new_reranked = fast_constructor(RerankedDocument)
 
 
 class Reranker:
@@ -99,42 +101,54 @@ class Reranker:
 
     def _score_pairs(self, queries: list[str], docs: list[str]) -> list[float]:
         """Sigmoid scores of (query, document) pairs.  Pairs go through in chunks: while the GPU scores one
-        chunk (the C call releases the GIL) a worker thread tokenises the next, so host tokenisation and
-        the cross-encoder pass overlap instead of adding up."""
+        chunk (the C call releases the GIL) a worker thread tokenises AND packs the next, so the calling
+        thread does nothing between two GPU passes but hand over three arrays — host tokenisation and the
+        cross-encoder pass overlap instead of adding up.  The first chunk is short: its tokenisation is the
+        only one the GPU has to wait for."""
         max_len = min(int(self.settings.truncate_length), self._max_len)
         with_types = self.model.cfg.type_vocab > 1
-        bounds = [(lo, min(lo + _PAIRS_PER_CHUNK, len(docs))) for lo in range(0, len(docs), _PAIRS_PER_CHUNK)]
+        n = len(docs)
+        bounds, lo = [], 0
+        while lo < n:
+            hi = min(lo + (_FIRST_CHUNK if lo == 0 and n > _PAIRS_PER_CHUNK else _PAIRS_PER_CHUNK), n)
+            bounds.append((lo, hi))
+            lo = hi
 
-        def tokenise(lo: int, hi: int):
-            return self.tokenizer.encode_pairs(queries[lo:hi], docs[lo:hi], max_len)
+        def prepare(lo: int, hi: int):
+            ids, types = self.tokenizer.encode_pairs(queries[lo:hi], docs[lo:hi], max_len)
+            parts = []
+            for a, b in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):
+                parts.append(pack_sequences(ids[a:b], types[a:b] if with_types else None))
+            return parts
 
         scores: list[float] = []
         if not bounds:
             return scores
         if self._tok_pool is None:
             self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rerank-tokenise")
-        pending = self._tok_pool.submit(tokenise, *bounds[0])
+        pending = self._tok_pool.submit(prepare, *bounds[0])
         for i in range(len(bounds)):
-            ids, types = pending.result()
+            parts = pending.result()
             if i + 1 < len(bounds):
-                pending = self._tok_pool.submit(tokenise, *bounds[i + 1])
-            for lo, hi in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):
-                probs = self.model.classify(ids[lo:hi], types[lo:hi] if with_types else None, sigmoid=True)
+                pending = self._tok_pool.submit(prepare, *bounds[i + 1])
+            for ids, types, cu in parts:
+                probs = self.model.classify_packed(ids, types, cu, sigmoid=True)
                 scores.extend(probs[:, 0].tolist())
         return scores
 
     @staticmethod
-    def _ranked(documents: list[Document], scores: list[float], top_n: int | None) -> list[RerankedDocument]:
-        # fields come from validated Document objects: skip a second validation pass (3200 documents
-        # per batch at top-100 make it the largest host cost after tokenisation)
+    def _ranked(documents: list[Document], scores: list[float], top_n: int | None, make=_new_reranked) -> list:
+        # fields come from validated Document objects (or fetched rows): no second validation pass, and the
+        # result objects are built once, by `make` — RerankedDocument unless the caller asked for its own
+        # result class (retrieval_executor.py does: it would only re-wrap every document otherwise)
         order = sorted(range(len(documents)), key=scores.__getitem__, reverse=True)  # stable: ties keep retrieval order
         if top_n is not None:
             order = order[:top_n]  # objects only for what is returned
         out = []
         for i in order:
             d = documents[i]
-            out.append(RerankedDocument.model_construct(doc_id=d.doc_id, title=d.title, content=d.content,
-                                                        category=d.category or "", score=float(scores[i])))
+            out.append(make(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category or "",
+                            score=float(scores[i])))
         return out
 
     def rerank(self, query: str, documents: list[Document], top_n: int | None = None) -> list[RerankedDocument]:
@@ -196,7 +210,9 @@ class Reranker:
         return scores
 
     def rerank_batch(self, queries: list[str], documents_batch: list[list[Document]],
-                     top_n: int | None = None) -> list[list[RerankedDocument]]:
+                     top_n: int | None = None, *, result_factory=None) -> list[list[RerankedDocument]]:
+        # `result_factory` (keyword-only, not in the reference's signature): build the result objects with this
+        # constructor instead of RerankedDocument — same five fields, passed as keywords
         if not self._loaded or self.model is None or self.tokenizer is None:
             raise RuntimeError("Reranker model not loaded")
         if len(queries) != len(documents_batch):
@@ -204,12 +220,14 @@ class Reranker:
                 f"Queries ({len(queries)}) and documents ({len(documents_batch)}) must have same length")
         if self._link is not None and self._link.world > 1 and self._link.rank == 0 and len(queries) > 1:
             per_query = self._sharded_scores(queries, documents_batch)
-            return [self._ranked(docs, sc, top_n) if docs else [] for docs, sc in zip(documents_batch, per_query)]
+            make = result_factory or _new_reranked
+            return [self._ranked(docs, sc, top_n, make) if docs else [] for docs, sc in zip(documents_batch, per_query)]
         flat_q = [q for q, docs in zip(queries, documents_batch) for _ in docs]
         flat_d = [d.content for docs in documents_batch for d in docs]
         scores = self._score_pairs(flat_q, flat_d) if flat_d else []
         out, pos = [], 0
+        make = result_factory or _new_reranked
         for docs in documents_batch:
-            out.append(self._ranked(docs, scores[pos:pos + len(docs)], top_n) if docs else [])
+            out.append(self._ranked(docs, scores[pos:pos + len(docs)], top_n, make) if docs else [])
             pos += len(docs)
         return out

@@ -13,6 +13,12 @@ One process per GPU: started under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in t
 --rank R --world W by hand, each process embeds the contiguous doc_id range sharded.shard_range gives it
 and writes its rows at their byte offset of the one output file; rank 0 writes the sidecar once every
 rank has left its `.done` marker.  No collective is involved.
+
+The ranks of one build share a BUILD ID (--build-id, else the launcher's TORCHELASTIC_RUN_ID): a marker
+is `{"build_id", "rank", "rows"}`, rank 0 accepts only markers of its own build whose row counts add up to
+the table, and no rank ever deletes another rank's marker — so neither a rank that finished before rank 0
+started nor the leftovers of a crashed earlier build can be mistaken for each other.  The sidecar of an
+earlier build is removed first and the new one appears atomically, last.
 """
 
 from __future__ import annotations
@@ -30,17 +36,34 @@ from ..components.embedding import EmbeddingGenerator
 from ..config import PipelineSettings
 
 
+def _read_marker(path: Path) -> dict | None:
+    try:
+        m = json.loads(path.read_text())
+        return m if isinstance(m, dict) else None
+    except (OSError, ValueError):
+        return None  # absent, or another rank is writing it right now (markers appear by rename, so: absent)
+
+
 def build_index(documents_dir: str, model: str, out: str, metric: str = "ip", field: str = "content",
                 batch_docs: int = 4096, device: int = 0, rank: int = 0, world: int = 1,
-                wait_seconds: float = 3600.0) -> tuple[int, int]:
+                wait_seconds: float = 3600.0, build_id: str | None = None) -> tuple[int, int]:
     """Embed every document (ordered by doc_id, which must be 0..n-1) and write `out` + `out`.json.
-    With world > 1 this process handles rows shard_range(n, rank, world) only.  Returns (rows, dim)."""
+    With world > 1 this process handles rows shard_range(n, rank, world) only and `build_id` (the same
+    string on every rank of this build) is required.  Returns (rows, dim)."""
     from ..sharded import shard_range
 
     if field not in ("content", "title"):
         raise ValueError("field must be 'content' or 'title'")
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world {world}")
+    build_id = build_id or os.environ.get("TORCHELASTIC_RUN_ID") or ("single" if world == 1 else None)
+    if not build_id:
+        raise ValueError("a multi-rank build needs one build id shared by its ranks: pass --build-id (torchrun "
+                         "exports TORCHELASTIC_RUN_ID, which is used when present)")
+    marker = lambda r: Path(f"{out}.part{r}.done")  # noqa: E731
+    marker(rank).unlink(missing_ok=True)            # only ever this rank's own marker
+    if rank == 0:
+        Path(str(out) + ".json").unlink(missing_ok=True)  # the rows are about to change under an old sidecar
     db = Path(documents_dir) / "documents.db"
     if not db.exists():
         raise FileNotFoundError(f"Document database not found at {db}")
@@ -54,10 +77,6 @@ def build_index(documents_dir: str, model: str, out: str, metric: str = "ip", fi
         raise ValueError(f"doc_id must run 0..n-1 to double as the index row number (found {lo_hi[0]}..{lo_hi[1]}, n={n})")
     dim = int(embedder._model.cfg.hidden)
     row_lo, row_hi = shard_range(n, rank, world)
-    marker = lambda r: Path(f"{out}.part{r}.done")  # noqa: E731
-    if rank == 0:
-        for r in range(world):
-            marker(r).unlink(missing_ok=True)
     t0 = time.time()
     fd = os.open(out, os.O_RDWR | os.O_CREAT, 0o644)  # every rank writes its own byte range of the one file
     try:
@@ -80,17 +99,28 @@ def build_index(documents_dir: str, model: str, out: str, metric: str = "ip", fi
         os.close(fd)
     con.close()
     embedder.unload()
-    marker(rank).write_text(str(row_hi - row_lo))
+    tmp = Path(f"{out}.part{rank}.done.tmp")
+    tmp.write_text(json.dumps({"build_id": build_id, "rank": rank, "rows": done - row_lo}))
+    os.replace(tmp, marker(rank))                   # a marker is either absent or complete
     if rank == 0:
         deadline = time.time() + wait_seconds
-        while not all(marker(r).exists() for r in range(world)):
+        while True:
+            marks = [_read_marker(marker(r)) for r in range(world)]
+            mine = [m if m and m.get("build_id") == build_id and m.get("rank") == r else None for r, m in enumerate(marks)]
+            if all(mine):
+                break
             if time.time() > deadline:
-                raise TimeoutError(f"ranks without a .done marker after {wait_seconds:.0f} s: "
-                                   f"{[r for r in range(world) if not marker(r).exists()]}")
+                raise TimeoutError(f"ranks without a .done marker of build {build_id!r} after {wait_seconds:.0f} s: "
+                                   f"{[r for r in range(world) if not mine[r]]}")
             time.sleep(0.05)
-        Path(str(out) + ".json").write_text(json.dumps(
+        written = sum(int(m["rows"]) for m in mine)
+        if written != n:
+            raise RuntimeError(f"the ranks of build {build_id!r} wrote {written} rows, the table has {n}")
+        side_tmp = Path(str(out) + ".json.tmp")
+        side_tmp.write_text(json.dumps(
             {"d": dim, "ntotal": n, "metric": metric, "model": model, "field": field, "ranks": world,
-             "seconds": round(time.time() - t0, 2)}))
+             "build_id": build_id, "seconds": round(time.time() - t0, 2)}))
+        os.replace(side_tmp, str(out) + ".json")
         for r in range(world):
             marker(r).unlink(missing_ok=True)
     return n, dim
@@ -107,9 +137,12 @@ def main() -> None:
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
     ap.add_argument("--rank", type=int, default=int(os.environ.get("RANK", "0")))
     ap.add_argument("--world", type=int, default=int(os.environ.get("WORLD_SIZE", "1")))
+    ap.add_argument("--build-id", default=None, help="one string shared by the ranks of this build "
+                                                     "(default: TORCHELASTIC_RUN_ID; required when --world > 1 without it)")
     a = ap.parse_args()
     device = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
-    n, d = build_index(a.documents_dir, a.model, a.out, a.metric, a.field, a.batch_docs, device, a.rank, a.world)
+    n, d = build_index(a.documents_dir, a.model, a.out, a.metric, a.field, a.batch_docs, device, a.rank, a.world,
+                       build_id=a.build_id)
     print(f"rank {a.rank}/{a.world}: wrote its rows of {a.out}: {n} x {d} fp32 ({a.metric})")
 
 

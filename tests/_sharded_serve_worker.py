@@ -48,8 +48,8 @@ def main() -> None:
         class cfg:
             type_vocab = 2
 
-        def classify(self, ids, types, sigmoid=True):
-            return np.array([[1.0 / (1 + len(s))] for s in ids], dtype=np.float32)
+        def classify_packed(self, ids, types, cu, sigmoid=True):   # packed sequences, as Reranker hands them over
+            return (1.0 / (1 + np.diff(cu).astype(np.float64))).astype(np.float32)[:, None]
 
     rr = Reranker(PipelineSettings(reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2"))
     rr.model, rr.tokenizer, rr._max_len, rr._loaded = StubModel(), HashTokenizer(30522), 512, True

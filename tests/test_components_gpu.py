@@ -250,13 +250,24 @@ def test_build_index_tool_embeds_documents_and_round_trips(gpu_required, tmp_pat
     import sys
     out3 = tmp_path / "faiss_index_3ranks.f32"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # leftovers of a crashed earlier build of the same file: a marker of another build and a stale sidecar
+    (tmp_path / "faiss_index_3ranks.f32.part1.done").write_text('{"build_id": "crashed-build", "rank": 1, "rows": 100}')
+    (tmp_path / "faiss_index_3ranks.f32.json").write_text('{"d": 384, "ntotal": 1, "metric": "ip"}')
     procs = [subprocess.Popen([sys.executable, "-m", "rag_inference_pipeline_amd.tools.build_index", "--documents-dir",
                                str(docs_dir), "--model", model, "--out", str(out3), "--batch-docs", "64",
-                               "--rank", str(r), "--world", "3", "--device", "0"], cwd=root) for r in range(3)]
-    assert all(p.wait(timeout=300) == 0 for p in procs)
+                               "--rank", str(r), "--world", "3", "--device", "0", "--build-id", "test-build-7"], cwd=root)
+             for r in (2, 1, 0)]   # rank 0 last: the others may well finish before it has started
+    try:
+        assert all(p.wait(timeout=300) == 0 for p in procs)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     a3, a1 = np.fromfile(out3, dtype=np.float32), np.fromfile(out, dtype=np.float32)
     assert a3.shape == a1.shape and np.abs(a3 - a1).max() < 2e-6   # other batch shapes, other GEMM paths: fp32 rounding
     import json
     side = json.loads((tmp_path / "faiss_index_3ranks.f32.json").read_text())
-    assert side["ntotal"] == 300 and side["d"] == 384 and side["ranks"] == 3
+    assert side["ntotal"] == 300 and side["d"] == 384 and side["ranks"] == 3 and side["build_id"] == "test-build-7"
+    with pytest.raises(ValueError, match="build id"):
+        build_index(str(docs_dir), model, str(tmp_path / "x.f32"), rank=1, world=2)
     assert not list(tmp_path.glob("*.done"))
