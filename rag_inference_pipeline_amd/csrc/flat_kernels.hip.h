@@ -162,7 +162,9 @@ struct ScanParams {
     float x_absmax, x_normmax, x_scale;  // corpus statistics behind the error bound, and the corpus' fp16 scale
     float* margin_out;     // [kQT] workgroup 0 publishes each query's band width for the resolve kernel
     uint32_t* lossy;       // [kQT] = epoch when the certificate is void from the start (query outside the range the
-                           // bound covers) or a workgroup could not hold a query's band
+                           // bound covers)
+    uint32_t* wg_lossy;    // [kQT][grid] = epoch when THIS workgroup could not hold a query's band and fell back to
+                           // its best k for that query (null: not recorded — sample pass)
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
 #endif
@@ -636,10 +638,18 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                                 const bool kp = idx < nn[j] && unord32((uint32_t)(kk[j][e] >> 32)) >= tnew;
                                 keep += (uint32_t)__popcll(__ballot(kp));
                             }
-                            if (keep > (uint32_t)(C - 16)) {  // the band does not fit: give it up for this query
+                            if (keep > (uint32_t)(C - 16)) {
+                                // The band does not fit: this workgroup keeps its best k for this query from here
+                                // on and says so.  Every row it drops scores below its k-th best of the moment,
+                                // hence at most its FINAL k-th best — entry k-1 of the list it emits — so the
+                                // resolve kernel voids the certificate only if that entry lies inside the final
+                                // band.  (A cluster of near-duplicates far below the top k overflows the band of
+                                // the one workgroup that scans it early, while its running k-th best is still low;
+                                // voiding the query for that sent 19 of 32 ordinary queries to the fallback on a
+                                // corpus with 400 copies of one row.)
                                 if (lane == 0) {
                                     mrg[q] = 0.f;
-                                    p.lossy[q] = p.epoch;
+                                    if (p.wg_lossy) p.wg_lossy[(size_t)q * gridDim.x + blockIdx.x] = p.epoch;
                                 }
                                 tnew = kscore;  // keep > C - 16 >= k implies full
                                 keep = (uint32_t)p.k;
@@ -1053,8 +1063,9 @@ struct ScreenCounters {     // cumulative, read back by rag_index_screen_stats
 //   (A) the k-th best approximate key over all workgroup lists, by the same tournament as the merge
 //       kernel, k rounds;
 //   (B) every listed row whose approximate score is within the query's margin of it — the band — is a
-//       candidate.  The certificate needs the WHOLE band: more than kp - 1 band rows, or a workgroup list
-//       that lies entirely inside the band (it may have been cut at kout), void it;
+//       candidate.  The certificate needs the WHOLE band: more than kp - 1 band rows, a workgroup list that
+//       lies entirely inside the band (it may have been cut at kout), or a workgroup that gave up its band
+//       for this query AND still has k rows inside the final band, void it;
 //   (C) canonical fp32 score of every candidate (the rago_dot chain of oracle/flat_oracle.c).  Each wave
 //       stages RPW candidate rows in LDS with coalesced 16-byte loads, all in flight together, then RPW
 //       lanes run the RPW fmaf chains side by side out of LDS; four waves cover 32 (16) candidates per
@@ -1072,6 +1083,7 @@ struct ResolveParams {
     const float* qnorm;      // canonical ||q||^2 (L2)
     long long id_offset;
     ScreenQueryState* qs;
+    const uint32_t* wg_lossy;  // [nq][n_lists] = epoch where a workgroup gave up part of a query's band
     uint32_t epoch;          // this search's id: the value "set" flags hold
     ScreenCounters* ctr;
     float* out_s;            // [nq][k]
@@ -1134,6 +1146,9 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
             }
         }
         if (pp == kout) s_cut = 1;  // the whole list is in the band: rows below its cut may be too
+        // a workgroup that gave up its band dropped nothing above its final k-th best (entry k-1): the
+        // certificate survives unless that entry is itself inside the band
+        else if (pp >= p.k && p.wg_lossy[(size_t)q * n_lists + l] == p.epoch) s_cut = 1;
     }
     __syncthreads();
     const int n = (int)min(s_cnt, (uint32_t)kp);                 // workgroup-uniform

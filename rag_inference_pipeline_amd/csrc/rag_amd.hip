@@ -146,6 +146,8 @@ int ensure_dyn_lds(const void* fn, size_t lds) {
 unsigned long long* g_stamps = nullptr;  // [2048][8], experiment build only
 #endif
 
+constexpr int kWgLossyLists = 2048;  // = 256 * kMergeMaxOwned, the largest scan grid the merge takes
+
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -199,6 +201,7 @@ struct rag_index {
     ragk::ScreenQueryState* sq = nullptr;
     ragk::ScreenCounters* sctr = nullptr;
     uint32_t screen_epoch = 0;   // id of the last two-stage search (ragk::ScreenQueryState flags are epoch-valued)
+    uint32_t* wg_lossy = nullptr;  // kQT x kWgLossyLists epoch-valued words: (query, workgroup) pairs that gave up a band
 
     // sample pass (starting thresholds for k >= kSampleMinK)
     ragk::u64* sample_heads = nullptr;  // kQT x kSampleLists workgroup maxima
@@ -379,6 +382,7 @@ int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_
     ss.stamps = nullptr;
 #endif
     if (ss.lossy) ss.lossy = h->sq->sample_lossy;
+    ss.wg_lossy = nullptr;  // the sample pass's lists only seed thresholds
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipLaunchKernelGGL(fn, dim3(lists), dim3(8 * 64), lds, st, ss);
     HIP_TRY(hipGetLastError());
@@ -455,6 +459,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.x_absmax = sp.x_normmax = sp.x_scale = 0.f;
         sp.margin_out = nullptr;
         sp.lossy = nullptr;
+        sp.wg_lossy = nullptr;
 #ifdef RAGK_STAMPS
         if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
         sp.stamps = enable ? nullptr : g_stamps;
@@ -611,6 +616,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.x_scale = h->x_scale;
     sp.margin_out = h->sq->margin;
     sp.lossy = h->sq->lossy;
+    sp.wg_lossy = h->wg_lossy;
 #ifdef RAGK_STAMPS
     if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
     sp.stamps = g_stamps;
@@ -659,6 +665,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         rp.qnorm = h->qnorm;
         rp.id_offset = h->id_offset;
         rp.qs = h->sq;
+        rp.wg_lossy = h->wg_lossy;
         rp.epoch = epoch;
         rp.ctr = h->sctr;
         rp.out_s = os;
@@ -781,7 +788,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.second);
         }
         void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev,
-                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr};
+                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr, h->wg_lossy};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin};
@@ -925,6 +932,8 @@ extern "C" int rag_index_set_screening(rag_index* h, int32_t mode) {
     HIP_TRY(hipMemset(h->sc_stats, 0, sizeof(ragk::ScreenCorpusStats)));
     HIP_TRY(hipMemset(h->sq, 0, sizeof(ragk::ScreenQueryState)));
     HIP_TRY(hipMemset(h->sctr, 0, sizeof(ragk::ScreenCounters)));
+    if (!h->wg_lossy && (rc = dev_alloc(&h->wg_lossy, (size_t)ragk::kQT * kWgLossyLists))) return rc;
+    HIP_TRY(hipMemset(h->wg_lossy, 0, (size_t)ragk::kQT * kWgLossyLists * sizeof(uint32_t)));
     if (h->cap_rows > 0 && (rc = dev_alloc(&h->X16, (size_t)h->cap_rows * d64))) return rc;
     h->d64 = d64;
     h->screen_on = true;

@@ -35,3 +35,12 @@ for mode in ("one-pass", "two-stage"):
         print(f"  {nme:14s} min {t[:, i].min():8.2f}  median {np.median(t[:, i]):8.2f}  max {t[:, i].max():8.2f} us")
     print(f"  prologue (median) {np.median(t[:,1]-t[:,0]):.2f} us; epilogue (median) {np.median(t[:,4]-t[:,3]):.2f} us; "
           f"loop-done spread {t[:,3].max()-t[:,3].min():.2f} us (p10 {np.percentile(t[:,3],10):.1f} p90 {np.percentile(t[:,3],90):.1f})", flush=True)
+    # who finishes late: by XCD (workgroups are dealt round-robin, b % 8) and by tail-round membership
+    done = t[:, 3]
+    print("  loop-done by b % 8:", " ".join(f"{done[x::8].mean():.1f}" for x in range(8)))
+    n_tiles = (rows + 31) // 32
+    left = n_tiles - (n_tiles // 2048) * 2048
+    if 0 < left < 256:
+        print(f"  loop-done, workgroups with a leftover tile (b < {left}): {done[:left].mean():.1f}; without: {done[left:].mean():.1f}")
+    q = np.argsort(done)
+    print("  ten latest workgroups:", q[-10:].tolist(), " ten earliest:", q[:10].tolist(), flush=True)

@@ -288,3 +288,65 @@ def test_randomised_corpora_two_stage_matches_oracle(gpu_required):
         idx.close()
     assert queries > 0 and fallbacks > 0      # the hard corpora did exercise the fallback ...
     assert fallbacks < queries                # ... and the easy ones did not
+
+
+def test_per_search_flags_do_not_leak_between_searches(gpu_required):
+    """The certificate / fallback words are epoch-valued (flat_kernels.hip.h ScreenQueryState): a flag is set for
+    the search whose id it holds, nothing clears them.  Alternate batches that force fallbacks (NaN and huge
+    queries, dense duplicates) with batches that need none, through one handle: every result exact, and the
+    fallback counter moves only for the batches that asked for it."""
+    rng = np.random.default_rng(42)
+    X = _unit(rng, 70_000, 128)
+    X[30_000:30_400] = X[7]                       # 400 exact duplicates of one row: a band that cannot fit
+    idx = _screened(X)
+    good = _unit(rng, 32, 128)
+    bad = good.copy()
+    bad[3, 5] = np.nan
+    bad[11, :] *= 1.0e30
+    bad[20] = X[7]                                # lands in the duplicate cluster
+    idx.screen_stats(reset=True)
+    seen = 0
+    for rnd in range(6):
+        Q = bad if rnd % 2 == 0 else good
+        _check(idx, X, Q, 10)
+        st = idx.screen_stats()
+        if rnd % 2 == 0:
+            assert st["fallbacks"] >= seen + 3, (rnd, st)
+        else:
+            assert st["fallbacks"] == seen, (rnd, st)   # a clean batch right after a dirty one: no stale flag
+        seen = st["fallbacks"]
+    # different batch sizes and k on the same handle, dirty then clean
+    _check(idx, X, bad[:5], 16)
+    seen = idx.screen_stats()["fallbacks"]
+    _check(idx, X, good[:5], 16)
+    _check(idx, X, good[:1], 1)
+    assert idx.screen_stats()["fallbacks"] == seen
+    idx.close()
+
+
+def test_randomised_large_shapes_full_rounds_and_tail_round(gpu_required):
+    """Seeded random shapes large enough for full rounds of the tile walk plus a random leftover (the
+    one-per-workgroup tail round), k on both sides of the warm-start limit (16), both metrics, one-pass and
+    two-stage on the same handle, ragged batches."""
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, SCREEN_OFF, FlatIndex
+    rng = np.random.default_rng(20261005)
+    for trial in range(int(os.environ.get("RAG_AMD_TEST_TRIALS_LARGE", "10"))):
+        d = int(rng.choice([8, 24, 40, 64]))
+        N = int(rng.integers(66_000, 330_000))
+        nq = int(rng.integers(1, 45))
+        k = int(rng.choice([1, 3, 10, 16, 17, 40, 100]))
+        metric = int(rng.integers(0, 2))
+        X = rng.standard_normal((N, d), dtype=np.float32)
+        if trial % 3 == 0:
+            X[N // 3: N // 3 + 5000] = X[:5000]          # ties across distant tiles
+        Q = rng.standard_normal((nq, d), dtype=np.float32)
+        idx = FlatIndex(d, metric)
+        idx.add(X)
+        Do, Io = oracle.search(X, Q, k, metric)
+        for mode in (SCREEN_OFF, SCREEN_FP16):
+            idx.set_screening(mode)
+            D, I = idx.search(Q, k)
+            msg = f"trial {trial}: N={N} d={d} nq={nq} k={k} metric={metric} mode={mode}"
+            np.testing.assert_array_equal(I, Io, err_msg=msg)
+            np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32), err_msg=msg)
+        idx.close()
