@@ -131,3 +131,46 @@ def test_one_device_rule_for_every_component(monkeypatch):
     assert EmbeddingGenerator(s).device == "cuda:6" and Reranker(s).device == "cuda:6"
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1)   # a group of one is the plain deployment
     assert resolve_gpu_device(s) == 3
+
+
+def test_document_store_fetches_a_batch_in_one_pass(tmp_path):
+    """fetch_documents_batch (reference document_store.py:278-302): per query in the requested order, unknown
+    ids silently dropped (:276), title/content cut to truncate_length characters (:59-84); ids shared by
+    several queries are read once."""
+    import sqlite3
+
+    from rag_inference_pipeline_amd.components.document_store import DocumentStore
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    d = tmp_path / "documents"
+    d.mkdir()
+    con = sqlite3.connect(d / "documents.db")
+    con.execute("CREATE TABLE documents (doc_id INTEGER PRIMARY KEY, title TEXT, content TEXT, category TEXT)")
+    con.executemany("INSERT INTO documents VALUES (?,?,?,?)",
+                    [(i, f"title {i}", f"content of document {i} " * 4, None if i % 2 else "cat") for i in range(2500)])
+    con.commit(); con.close()
+    store = DocumentStore(PipelineSettings(DOCUMENTS_DIR=str(d)))
+    batch = [[5, 3, 99999, 3, 2499], [], [3, 7], list(range(2000, 100, -1))]     # > 900 distinct ids: several IN (...) passes
+    got = store.fetch_documents_batch(batch, truncate_length=12)
+    assert [[x.doc_id for x in docs] for docs in got] == [[5, 3, 3, 2499], [], [3, 7], list(range(2000, 100, -1))]
+    assert got[0][0].title == "title 5" and got[0][0].content == "content of d" and got[0][0].category is None
+    assert got[3][0].category == "cat" and got[2][0].category is None and len(got[3][0].content) == 12
+    full = store.fetch_documents([7, 123456, 1])
+    assert [x.doc_id for x in full] == [7, 1] and full[0].content == "content of document 7 " * 4
+    assert store.fetch_documents([]) == [] and store.fetch_documents_batch([]) == []
+    store.close_all()
+
+
+def test_fast_constructor_builds_what_validation_builds():
+    """components/schemas.fast_constructor: the objects a rerank batch returns are ordinary model instances —
+    equal to validated ones, dumpable, serialisable, accepted by a validating parent model."""
+    from rag_inference_pipeline_amd.components.schemas import RerankedDocument, fast_constructor
+    from rag_inference_pipeline_amd.schemas import RetrievalDocument, RetrievalResponseItem
+    for cls in (RerankedDocument, RetrievalDocument):
+        make = fast_constructor(cls)
+        a = make(doc_id=7, title="t", content="c", category="", score=0.25)
+        b = cls(doc_id=7, title="t", content="c", score=0.25)
+        assert a == b and a.model_dump() == b.model_dump() and a.model_dump_json() == b.model_dump_json()
+        assert a.model_fields_set == {"doc_id", "title", "content", "category", "score"} and a.model_copy() == b
+    item = RetrievalResponseItem(request_id="r", docs=[fast_constructor(RetrievalDocument)(
+        doc_id=1, title="", content="", category="", score=1.0)], compressed_docs=None)
+    assert item.docs[0].doc_id == 1 and '"score":1.0' in item.model_dump_json()
