@@ -114,6 +114,9 @@ __device__ __forceinline__ void wave_sort_desc(u64 (&key)[NQ][E], int lane) {
 }
 
 // ---- K1: scan + select ----------------------------------------------------------------------
+// (The corpus stream uses plain loads.  With the non-temporal hint — a natural idea for bytes read once per
+// batch — the scan ran at HALF the rate, 9.96 ms instead of 5.14 ms on 10M x 768: the four 16-byte pieces of a
+// row's 128-byte line are requested by four separate instructions and rely on the vector L1 to merge them.)
 
 // One ring slot (32 bytes of a row across the two lane halves) times the matching query fragment.
 template <int P>
