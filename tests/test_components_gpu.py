@@ -78,6 +78,45 @@ def test_faiss_only_profile_end_to_end(gpu_required, corpus, tmp_path):
     assert not registry.get("faiss_store").is_loaded
 
 
+def test_binary_embedding_field_through_the_gpu_index(gpu_required, corpus):
+    """the optional `embedding_f32` field (little-endian fp32 bytes; base64 text in JSON) carries the
+    same query as the reference's list of floats — through the real index on the GPU both forms, mixed in one
+    batch, return the oracle's ids and score bits, and the JSON round trip of the request item keeps the bytes."""
+    import base64
+    X, path = corpus
+    settings = PipelineSettings(FAISS_INDEX_PATH=str(path), faiss_dim=384, retrieval_batch_size=16,
+                                retrieval_max_batch_delay_ms=20, DISABLE_CACHE_FOR_PROFILING="true")
+    store = FAISSStore(settings)
+    store.load()
+    from rag_inference_pipeline_amd.component_registry import ComponentRegistry
+    registry = ComponentRegistry()
+    registry.register("faiss_store", store)
+    Q = oracle.synth_rows(77, 0, 9, 384)
+
+    async def run():
+        ex = RetrievalExecutor(registry, settings)
+        await ex.start()
+        items = []
+        for i in range(9):
+            if i % 2 == 0:   # binary form, as it arrives from JSON: base64 text -> bytes by the validator
+                raw = RetrievalRequestItem.model_validate_json(
+                    '{"request_id": "r%d", "query": "", "embedding_f32": "%s"}' % (i, base64.b64encode(Q[i].tobytes()).decode()))
+                assert raw.embedding_f32 == Q[i].tobytes()
+                items.append(raw)
+            else:
+                items.append(RetrievalRequestItem(request_id=f"r{i}", query="", embedding=Q[i].tolist()))
+        outs = await asyncio.gather(*[ex.process_request(it) for it in items])
+        await ex.stop()
+        return outs
+
+    outs = asyncio.run(run())
+    Do, Io = oracle.search(X, Q, 10)
+    for i, item in enumerate(outs):
+        assert item.request_id == f"r{i}" and [d.doc_id for d in item.docs] == Io[i].tolist()
+        np.testing.assert_array_equal(np.array([d.score for d in item.docs], np.float32).view(np.uint32), Do[i].view(np.uint32))
+    store.unload()
+
+
 # ---- embedder / reranker / whole retrieval node --------------------------------------------------------
 
 def _hf_checkpoint(tmp_path, head):
