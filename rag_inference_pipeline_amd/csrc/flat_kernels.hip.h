@@ -952,9 +952,9 @@ __global__ __launch_bounds__(64 * WAVES) void tournament_merge_kernel(const Src 
 //
 // Stage 1 (scan_topk_kernel<P = 1>) reads a scaled fp16 copy of the corpus — half the bytes of the
 // fp32 scan, and the matrix work drops to 1/16 — and keeps, per query and workgroup, every row whose
-// *approximate* score lies within 2 eps of the workgroup's running k-th best.  screen_collect_kernel
+// *approximate* score lies within 2 eps of the workgroup's running k-th best.  screen_resolve_kernel
 // then gathers the rows within 2 eps of the global k-th best approximate score (at most 239 of them),
-// and stage 2 recomputes their canonical fp32 scores and ranks them.  With |approx - exact| <= eps
+// recomputes their canonical fp32 scores and ranks them.  With |approx - exact| <= eps
 // for every row, the k rows with the best approximate scores have exact scores >= a_k - eps, so the
 // k-th exact score is >= a_k - eps, so every true top-k row has approx >= a_k - 2 eps: it is in the
 // band.  The result is therefore the exact top-k (bit-identical to the one-pass fp32 search) whenever

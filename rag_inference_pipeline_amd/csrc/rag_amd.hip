@@ -553,8 +553,8 @@ int screen_capacity(int d64, int k) {
 
 int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st) {
     using namespace ragk;
-    // candidate slots per query: always the most the finalize sort takes (empty slots cost nothing: the
-    // collect kernel packs candidates at the front, verify groups without one return at once), so a dense
+    // candidate slots per query: always the most the resolve kernel's final sort takes (empty slots cost
+    // nothing: candidates are packed at the front of an LDS list and scored 32 at a time), so a dense
     // neighbourhood has to put 240 rows inside the band before the fp32 fallback is needed
     const int kp = 240;
     const int cap = screen_capacity(h->d64, k);
