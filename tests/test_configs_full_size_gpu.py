@@ -133,3 +133,37 @@ def test_config_c_rerank_top100_to_top10_3200_pairs(corpus_and_index, encoded_qu
         for r, j in enumerate(order):                                # same rank unless the oracle's neighbours are within tolerance
             if (r == 0 or ws[r - 1] - ws[r] > 1e-4) and (r == 99 or ws[r] - ws[r + 1] > 1e-4):
                 assert full[b][r].doc_id == int(I[b][j])
+
+
+def test_config_b_size_on_the_surveys_gaussian_corpus(gpu_required):
+    """SURVEY 8(d)'s synthetic inputs, literally: corpus rows from `np.random.default_rng(1234 + chunk)
+    .standard_normal` in chunks, L2-normalised; queries from `default_rng(4321)`; a second query set of perturbed
+    corpus rows (x + 0.05 noise, renormalised) whose true top-1 is known a priori.  1M x 384, batch 32, k = 10,
+    one-pass and two-stage, against the oracle over the whole corpus.  (bench.py uses the integer-hash generator
+    instead because the CPU must regenerate single rows of a 10M-row corpus bit-exactly; this test holds the same
+    kernels to the oracle on the distribution the survey names.)"""
+    from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, SCREEN_OFF, FlatIndex
+    chunk = 250_000
+    idx = FlatIndex(D)
+    parts = []
+    for c in range(N // chunk):
+        x = np.random.default_rng(1234 + c).standard_normal((chunk, D), dtype=np.float32)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        parts.append(x.astype(np.float32))
+        idx.add(parts[-1])
+    X = np.concatenate(parts)
+    q = np.random.default_rng(4321).standard_normal((B, D), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    rows = np.random.default_rng(99).integers(0, N, size=B)
+    p = X[rows] + 0.05 * np.random.default_rng(5).standard_normal((B, D), dtype=np.float32)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    for Q in (q.astype(np.float32), p.astype(np.float32)):
+        Do, Io = oracle.search(X, Q, 10)
+        for mode in (SCREEN_OFF, SCREEN_FP16):
+            idx.set_screening(mode)
+            Dg, Ig = idx.search(Q, 10)
+            np.testing.assert_array_equal(Ig, Io)
+            np.testing.assert_array_equal(Dg.view(np.uint32), Do.view(np.uint32))
+    assert Io[:, 0].tolist() == rows.tolist()      # the perturbed rows come back as their own nearest neighbour
+    assert idx.screen_stats()["fallbacks"] == 0
+    idx.close()
