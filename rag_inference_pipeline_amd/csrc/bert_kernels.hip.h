@@ -741,61 +741,71 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x6_kernel(const GemmX6Params p
                       p.ldr, p.C, p.ldc, p.act);
 }
 
-// Small-M GEMM: 64 x 64 x 64 tiles, EIGHT waves.  Waves 0-3 (2 x 2 over the tile) multiply columns 0-31 of
-// every staged K-tile, waves 4-7 columns 32-63, so each SIMD holds two waves whose LDS waits and barrier
-// waits hide behind each other's MFMAs (with one wave per SIMD half of each K-step was exposed latency);
-// the two partial tiles are added through LDS at the end in a fixed order.  Same split-K / epilogue
-// contract as gemm_nt_kernel.  Requires k_per_split % 64 == 0.
+// Small-M GEMM: 64 x (32 WN) x 64 tiles, 4 WN waves (WN = 2: 64 x 64 tiles, eight waves; WN = 3: 64 x 96, twelve).
+// Waves 0 .. 2WN-1 (2 x WN over the tile) multiply columns 0-31 of every staged K-tile, the other 2WN waves
+// columns 32-63, so each SIMD holds waves whose LDS waits and barrier waits hide behind each other's MFMAs
+// (with one wave per SIMD half of each K-step was exposed latency); the two partial tiles are added through
+// LDS at the end in a fixed order.  Same split-K / epilogue contract as gemm_nt_kernel.  Requires
+// k_per_split % 64 == 0.
+// WN = 3 exists for one shape class: at 450 tokens a GEMM with N = 3072 (bge-base FFN input projection) is
+// 7 x 48 = 336 tiles of 64 x 64 on 256 CUs — the 80 CUs that get two take twice as long and everyone waits
+// (33.9 us for 13 us of matrix work per tile); 7 x 32 = 224 tiles of 64 x 96 all run at once, each 1.5x the work.
 constexpr int SBK = 64, SLD = 68;  // 68 r mod 64 = 4 r: 16 rows of a ds_read_b128 group hit 16 distinct slots
 
-__global__ __launch_bounds__(512) void gemm_nt_small_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float As_[2][64 * SLD];
-    __shared__ __attribute__((aligned(16))) float Ws_[2][64 * SLD];
+template <int WN>
+__global__ __launch_bounds__(256 * WN) void gemm_nt_small_kernel(const GemmParams p) {
+    constexpr int BN = 32 * WN, ROWS = 64 + BN, NT = 256 * WN;   // staged rows per K-tile: A rows 0..63, W rows 64..
+    constexpr int NI = (ROWS * 16 + NT - 1) / NT;                // float4 per thread per K-tile (4; WN = 3: the last pass is partial)
+    __shared__ __attribute__((aligned(16))) float T_[2][ROWS * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int kh = wave / (2 * WN), wm = (wave % (2 * WN)) / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const bool split = gridDim.z > 1;
 
-    const int srow = tid >> 4, scol = (tid & 15) * 4;  // 32 rows x 16 float4 per pass, 2 passes
-    const float* ag[2];
-    const float* wg[2];
+    // staging: item i of the K-tile = (row i / 16, float4 column i % 16); thread tid takes items tid + NT j
+    const float* src[NI];
+    int dst[NI];
+    bool have[NI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int am = m0 + srow + 32 * j;
-        am = am < p.M ? am : p.M - 1;
-        int wr = n0 + srow + 32 * j;
-        wr = wr < p.N ? wr : p.N - 1;
-        ag[j] = p.A + (size_t)am * p.lda + kbeg + scol;
-        wg[j] = p.W + (size_t)wr * p.ldw + kbeg + scol;
+    for (int j = 0; j < NI; ++j) {
+        const int item = tid + NT * j, row = item >> 4, col = (item & 15) * 4;
+        have[j] = (ROWS * 16) % NT == 0 || item < ROWS * 16;  // WN = 2: every pass is full, known at compile time
+        const int rr = have[j] ? row : 0;
+        if (rr < 64) {
+            int am = m0 + rr;
+            am = am < p.M ? am : p.M - 1;
+            src[j] = p.A + (size_t)am * p.lda + kbeg + col;
+        } else {
+            int wr = n0 + rr - 64;
+            wr = wr < p.N ? wr : p.N - 1;
+            src[j] = p.W + (size_t)wr * p.ldw + kbeg + col;
+        }
+        dst[j] = rr * SLD + col;
     }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     const int nk = (kend - kbeg) / SBK;
-    f32x4 ra0[2], rw0[2], ra1[2], rw1[2];
-    auto load_tile = [&](f32x4 (&ra)[2], f32x4 (&rw)[2], int kt) {
+    f32x4 r0[NI], r1[NI];
+    auto load_tile = [&](f32x4 (&rg)[NI], int kt) {
         if (kt < nk) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                ra[j] = *reinterpret_cast<const f32x4*>(ag[j] + (size_t)kt * SBK);
-                rw[j] = *reinterpret_cast<const f32x4*>(wg[j] + (size_t)kt * SBK);
-            }
+            for (int j = 0; j < NI; ++j)
+                if (have[j]) rg[j] = *reinterpret_cast<const f32x4*>(src[j] + (size_t)kt * SBK);
         }
     };
-    auto write_tile = [&](const f32x4 (&ra)[2], const f32x4 (&rw)[2], int buf) {
+    auto write_tile = [&](const f32x4 (&rg)[NI], int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<f32x4*>(&As_[buf][(srow + 32 * j) * SLD + scol]) = ra[j];
-            *reinterpret_cast<f32x4*>(&Ws_[buf][(srow + 32 * j) * SLD + scol]) = rw[j];
-        }
+        for (int j = 0; j < NI; ++j)
+            if (have[j]) *reinterpret_cast<f32x4*>(&T_[buf][dst[j]]) = rg[j];
     };
     auto multiply_tile = [&](int buf) {
-        const float* As = &As_[buf][(wm * 32 + r) * SLD + kh * 32 + 4 * h];
-        const float* Ws = &Ws_[buf][(wn * 32 + r) * SLD + kh * 32 + 4 * h];
+        const float* As = &T_[buf][(wm * 32 + r) * SLD + kh * 32 + 4 * h];
+        const float* Ws = &T_[buf][(64 + wn * 32 + r) * SLD + kh * 32 + 4 * h];
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
             const f32x4 af = *reinterpret_cast<const f32x4*>(As + kg * 8);
@@ -804,39 +814,40 @@ __global__ __launch_bounds__(512) void gemm_nt_small_kernel(const GemmParams p) 
             for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t], af[t], acc, 0, 0, 0);
         }
     };
-    load_tile(ra0, rw0, 0);
-    load_tile(ra1, rw1, 1);
-    write_tile(ra0, rw0, 0);
-    load_tile(ra0, rw0, 2);
+    load_tile(r0, 0);
+    load_tile(r1, 1);
+    write_tile(r0, 0);
+    load_tile(r0, 2);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
         if (kt + 1 < nk) {  // block-uniform
-            write_tile(ra1, rw1, 1);
-            load_tile(ra1, rw1, kt + 3);
+            write_tile(r1, 1);
+            load_tile(r1, kt + 3);
         }
         multiply_tile(0);
         __syncthreads();
         if (kt + 1 < nk) {
             if (kt + 2 < nk) {
-                write_tile(ra0, rw0, 0);
-                load_tile(ra0, rw0, kt + 4);
+                write_tile(r0, 0);
+                load_tile(r0, kt + 4);
             }
             multiply_tile(1);
             __syncthreads();
         }
     }
 
-    // add the two K-halves: waves 4-7 park their tile in LDS (the staging buffers are free after the
-    // loop's last barrier), waves 0-3 add it to theirs (low half + high half, always in that order)
-    float* xch = &As_[0][0];  // 4 waves x 16 regs x 64 lanes x 4 B = 16 KB <= sizeof(As_[0])
+    // add the two K-halves: the upper-half waves park their tile in LDS (the staging buffers are free after the
+    // loop's last barrier), the lower-half waves add it to theirs (low half + high half, always in that order)
+    float* xch = &T_[0][0];  // 2 WN waves x 16 regs x 64 lanes x 4 B = 8 WN KB <= sizeof(T_[0])
+    const int slot = wave % (2 * WN);
     if (kh == 1) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xch[((wave & 3) * 16 + i) * 64 + lane] = acc[i];
+        for (int i = 0; i < 16; ++i) xch[(slot * 16 + i) * 64 + lane] = acc[i];
     }
     __syncthreads();
     if (kh == 1) return;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += xch[((wave & 3) * 16 + i) * 64 + lane];
+    for (int i = 0; i < 16; ++i) acc[i] += xch[(slot * 16 + i) * 64 + lane];
 
     float* Cz = p.C + (split ? (size_t)blockIdx.z * p.M * p.ldc : 0);
     store_tile_rows(acc, m0 + wm * 32 + r, n0 + wn * 32, h, p.M, p.N, p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);

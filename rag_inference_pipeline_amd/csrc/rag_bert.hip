@@ -114,7 +114,7 @@ struct WRef {
 // runs on the bf16 matrix cores with fp32 accuracy (split-bf16 image), or takes fp16 inputs when the
 // model was created with RAG_GEMM_F16, or stays on the fp32 MFMA (RAG_GEMM_F32_STRICT).
 int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* bias, const float* R,
-                int ldr, float* C, int ldc, int M, int N, int K, int act, hipStream_t st) {
+                int ldr, float* C, int ldc, int M, int N, int K, int act, hipStream_t st, int n_cus = 256) {
     const float* W = Wr.w;
     const _Float16* W16 = Wr.w16;
     if (M <= 0) return RAG_OK;
@@ -143,10 +143,17 @@ int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* b
         ragb::gemm_nt_kernel<2, 2><<<grid, dim3(256), 0, st>>>(g);
     } else {
         dim3 grid((N + 63) / 64, (M + 63) / 64, 1);
-        if (K % ragb::SBK == 0)
-            ragb::gemm_nt_small_kernel<<<grid, dim3(512), 0, st>>>(g);
-        else
+        // more 64 x 64 tiles than CUs but no more 64 x 96 tiles than CUs: one round of bigger tiles instead of
+        // a full round plus a mostly empty one (bge-base FFN input projection at 450 tokens: 336 -> 224 tiles)
+        const long long t64 = (long long)grid.x * grid.y, t96 = (long long)((N + 95) / 96) * grid.y;
+        if (K % ragb::SBK == 0 && t64 > n_cus && t96 <= n_cus) {
+            grid.x = (N + 95) / 96;
+            ragb::gemm_nt_small_kernel<3><<<grid, dim3(768), 0, st>>>(g);
+        } else if (K % ragb::SBK == 0) {
+            ragb::gemm_nt_small_kernel<2><<<grid, dim3(512), 0, st>>>(g);
+        } else {
             ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
+        }
     }
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
@@ -196,7 +203,7 @@ int launch_gemm_ln(const float* A, int lda, const WRef& Wr, int ldw, const float
         splits = (K + g.k_per_split - 1) / g.k_per_split;
         dim3 grid((N + 63) / 64, (M + 63) / 64, splits);
         if (small8)
-            ragb::gemm_nt_small_kernel<<<grid, dim3(512), 0, st>>>(g);
+            ragb::gemm_nt_small_kernel<2><<<grid, dim3(512), 0, st>>>(g);
         else
             ragb::gemm_nt_kernel<1, 1><<<grid, dim3(256), 0, st>>>(g);
         RAGC_HIP_TRY(hipGetLastError());
@@ -249,7 +256,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             return WRef{lw[wsrc[i]], lh ? lh[i] : nullptr, h->wx.empty() ? nullptr : h->wx[(size_t)4 * l + i]};
         };
         // QKV projection
-        rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st);
+        rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st, h->n_cus);
         if (rc) return rc;
         if (h->valu_attention) {
             if (dh == 32)
@@ -268,7 +275,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         rc = launch_gemm_ln(h->ctx, H, wref(1), H, lw[3], h->x, h->y, lw[4], lw[5], h->x, T, H, H, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
         // feed-forward: act(x W1ᵀ + b1) W2ᵀ + b2 + residual, LayerNorm
-        rc = launch_gemm(h->x, H, wref(2), H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st);
+        rc = launch_gemm(h->x, H, wref(2), H, lw[7], nullptr, 0, h->ffn, I, T, I, H, act, st, h->n_cus);
         if (rc) return rc;
         rc = launch_gemm_ln(h->ffn, I, wref(3), I, lw[9], h->x, h->y, lw[10], lw[11], h->x, T, H, I, c.ln_eps, h->n_cus, st);
         if (rc) return rc;
