@@ -89,6 +89,11 @@ __global__ __launch_bounds__(512) void gemm_nt_x6v2_kernel(const GemmX6Params p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bf16x4 hi, mid, lo;
+#ifdef V2_NO_SPLIT
+                    hi = __builtin_bit_cast(bf16x4, ((const uint2*)&ra[j])[0]);   // wrong values, no vector work
+                    mid = __builtin_bit_cast(bf16x4, ((const uint2*)&ra[j])[1]);
+                    lo = hi;
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = ra[j][e];
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x6v2_kernel(const GemmX6Params p)
                         mid[e] = (__bf16)r1;
                         lo[e] = (__bf16)(r1 - (float)mid[e]);
                     }
+#endif
                     const int o = (32 * pw + prow + 8 * j) * XLD + pcol;
                     *reinterpret_cast<bf16x4*>(st + o) = hi;
                     *reinterpret_cast<bf16x4*>(st + 128 * XLD + o) = mid;
