@@ -980,9 +980,11 @@ __global__ __launch_bounds__(64) void attention_kernel(const float* qkv, const i
 //                               from LDS by column -> no shuffle, no transpose of P.
 // The VALU version this replaces issued ~200 vector instructions per key per wave and ran at 40 % of the
 // VALU issue rate (12 % of cross-encoder time); here a 32-key tile is 16..32 + 16..32 MFMAs.
+// first_only: only each sequence's FIRST token is a query and its output row goes to ctx[s] (one row per
+// sequence) — the last layer of a model whose output reads first tokens only (CLS pooling, classifier head).
 template <int DH>
 __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, const int* cu, float* ctx, int H, int heads,
-                                                            float scale) {
+                                                            float scale, int first_only = 0) {
     constexpr int KLD = DH + 4;  // padded K rows: conflict-free ds_read_b128 fragments
     __shared__ __attribute__((aligned(16))) float Ks[32 * KLD];
     __shared__ __attribute__((aligned(16))) float Vs[32 * DH];
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
     const int t0 = cu[s], L = cu[s + 1] - t0;
     if (qb * 32 >= L) return;
     const int qidx = qb * 32 + r;
-    const bool qvalid = qidx < L;
+    const bool qvalid = first_only ? qidx == 0 : qidx < L;
     const size_t ld = (size_t)3 * H;
 
     // Q fragments: lane (r,h) holds Q[qidx][8 s + 4 h .. + 3] for every 8-column step s
@@ -1077,7 +1079,7 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
     }
     if (qvalid) {
         const float inv = 1.0f / den;
-        float* orow = ctx + (size_t)(t0 + qidx) * H + head * DH;
+        float* orow = ctx + (size_t)(first_only ? s : t0 + qidx) * H + head * DH;
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
@@ -1089,13 +1091,15 @@ __global__ __launch_bounds__(64) void attention_mfma_kernel(const float* qkv, co
 }
 
 // ---- pooling ----------------------------------------------------------------------------------------
-// mode 0: mean over the sequence's tokens, mode 1: first token.  normalize: divide by the L2 norm
+// mode 0: mean over the sequence's tokens, mode 1: first token, mode 2: x holds one row per sequence.
+// normalize: divide by the L2 norm
 // (torch.nn.functional.normalize: x / max(||x||, 1e-12)).
 __global__ __launch_bounds__(256) void pool_kernel(const float* x, const int* cu, float* out, int H, int mode,
                                                    int normalize) {
     __shared__ float red[4];
     const int s = blockIdx.x, tid = threadIdx.x;
-    const int t0 = cu[s], L = cu[s + 1] - t0;
+    // mode 2: x is already one row per sequence ([nseq][H], the last layer ran on first tokens only)
+    const int t0 = mode == 2 ? s : cu[s], L = mode == 2 ? 1 : cu[s + 1] - t0;
     float v[4];  // H <= 1024: 4 columns per thread
     float ss = 0.f;
 #pragma unroll

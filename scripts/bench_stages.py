@@ -27,9 +27,15 @@ def mode_peak(gemm_dtype, tokens):
     return BF16_MFMA_PEAK_TF / 6.0, "bf16 MFMA, six products per fp32 product (2.5 PF/s / 6 = 417 TF/s fp32-equivalent)"
 
 
-def gemm_flops(cfg, T, nseq, head):
+def gemm_flops(cfg, T, nseq, head, first_only=False):
+    """GEMM flops the forward pass EXECUTES.  With an output that reads first tokens only (CLS pooling, classifier
+    head) the last layer's output projection and feed-forward run on nseq rows, not T (rag_bert.hip)."""
     H, I = cfg.hidden, cfg.intermediate
-    return 2 * (3 * H * H + H * H + 2 * H * I) * cfg.n_layers * T + (2 * H * H * nseq if head else 0)
+    per_token = 2 * (3 * H * H + H * H + 2 * H * I)
+    total = per_token * cfg.n_layers * T + (2 * H * H * nseq if head else 0)
+    if first_only and nseq < T:
+        total -= 2 * (H * H + 2 * H * I) * (T - nseq)
+    return total
 
 
 def attn_flops(cfg, lens):
@@ -78,7 +84,7 @@ def run(name, cfg, lens, out_kind, reps=10, cpu_sample=0, threads=16, gemm_dtype
         go()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    gf = gemm_flops(cfg, T, nseq, cfg.head != "none")
+    gf = gemm_flops(cfg, T, nseq, cfg.head != "none", first_only=out_kind != _native.BERT_OUT_MEAN and out_kind != _native.BERT_OUT_HIDDEN)
     res = {"stage": name, "nseq": nseq, "tokens": T, "max_len": L, "ms_per_batch": ms, "gemm_gflop": gf / 1e9,
            "attention_gflop": attn_flops(cfg, lens) / 1e9, "gemm_tflops_end_to_end": gf / ms / 1e9,
            "mfma_peak_tflops_of_this_mode": mode_peak(gemm_dtype, T)[0], "mfma_peak_basis": mode_peak(gemm_dtype, T)[1],
