@@ -788,8 +788,9 @@ struct ShardListSrc {  // per-shard (score, id) results: shard l's element (q * 
     __device__ __forceinline__ u64 get(int q, int l, int pos) const {
         const size_t e = (size_t)q * k + pos;
         const long long id = ids[(size_t)l * id_stride + e];
+        const float s = scores[(size_t)l * score_stride + e];  // both loads in flight together: the buffer has just
+                                                               // arrived from other GPUs and is cold in this L2
         if (id < 0 || id > 0xFFFFFFFEll) return 0ull;  // padding; ids beyond 32 bits cannot come from rag_index (set_id_offset refuses them)
-        const float s = scores[(size_t)l * score_stride + e];
         return make_key(metric ? -s : s, (uint32_t)id);  // L2 lists carry ascending distances
     }
 };
