@@ -1092,7 +1092,15 @@ struct ResolveParams {
     ScreenCounters* ctr;
     float* out_s;            // [nq][k]
     long long* out_i;
+#ifdef RAGK_STAMPS
+    unsigned long long* stamps;  // experiment build: [nq][8] phase stamps
+#endif
 };
+#ifdef RAGK_STAMPS
+#define RAGK_RSTAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RAGK_RSTAMP(i) do { } while (0)
+#endif
 
 __host__ __device__ inline int resolve_rows_per_wave(int d8) { return d8 <= 1024 ? 8 : 4; }
 __host__ __device__ inline size_t resolve_lds_bytes(int d8, int n_lists, int look, int kp) {
@@ -1115,6 +1123,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     __shared__ uint32_t s_cnt, s_cut;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_lists = p.n_lists, look = p.look, kp = p.kp, kout = p.src.k;
+    RAGK_RSTAMP(0);
 
     stage_heads<KeyListSrc, 256>(p.src, q, n_lists, look, ahead, tid);
     for (int c = tid; c < p.d8; c += 256) qv[c] = c < p.d ? p.Q[(size_t)q * p.d + c] : 0.f;
@@ -1124,6 +1133,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     }
     __syncthreads();
 
+    RAGK_RSTAMP(1);
     // ---- (A) k-th best approximate key (TW == 1: wave 0 alone plays the tournament)
     if (TW == 4 || wave == 0) {
         const u64 last = tournament_rounds<KeyListSrc, OWN, TW, true>(p.src, q, n_lists, p.k, kout, look, ahead, wmax, tid,
@@ -1133,6 +1143,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     __syncthreads();
     const u64 kth = s_kth;
 
+    RAGK_RSTAMP(2);
     // ---- (B) the band
     const float margin = p.qs->margin[q];
     const float thr = kth != 0ull ? unord32((uint32_t)(kth >> 32)) - margin : -__builtin_inff();
@@ -1158,6 +1169,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
     const int n = (int)min(s_cnt, (uint32_t)kp);                 // workgroup-uniform
     const bool overflow = s_cnt >= (uint32_t)kp || s_cut != 0;
 
+    RAGK_RSTAMP(3);
     // ---- (C) canonical scores.  d8 / 4 <= 32 * 64 / RPW float4 per row: a lane holds NU of each of its wave's rows.
     constexpr int NU = 32 / RPW;
     const int d4 = p.d8 / 4;
@@ -1213,6 +1225,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
         }
     }
     __syncthreads();
+    RAGK_RSTAMP(4);
     if (wave != 0) return;
 
     // ---- (D) certificate, ranking, results: one wave, kp <= 256 keys (the usual few dozen take the
@@ -1279,6 +1292,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
             atomicMax(&p.ctr->max_err_ratio_bits, __float_as_uint(worst / eps));
         }
     }
+    RAGK_RSTAMP(5);
 }
 
 // ---- helpers ----------------------------------------------------------------------------------

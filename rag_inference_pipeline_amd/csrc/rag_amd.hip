@@ -675,6 +675,9 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         rp.ctr = h->sctr;
         rp.out_s = os;
         rp.out_i = oi;
+#ifdef RAGK_STAMPS
+        rp.stamps = g_stamps ? g_stamps + 2048 * 4 : nullptr;  // second half of the stamp buffer
+#endif
         const size_t rlds = resolve_lds_bytes(h->d8, grid, look, kp);
         using ResolveFn = void (*)(const ResolveParams);
         ResolveFn resolve;
@@ -1170,6 +1173,13 @@ extern "C" int rag_debug_scan_stamps(unsigned long long* out, int32_t n_wg) {
     if (!g_stamps || !out || n_wg <= 0 || n_wg > 2048) return RAG_ERR_INVALID_ARG;
     if (hipDeviceSynchronize() != hipSuccess) return RAG_ERR_HIP;
     if (hipMemcpy(out, g_stamps, (size_t)n_wg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return RAG_ERR_HIP;
+    return RAG_OK;
+}
+// phase stamps of the last resolve launch, [nq][8]
+extern "C" int rag_debug_resolve_stamps(unsigned long long* out, int32_t nq) {
+    if (!g_stamps || !out || nq <= 0 || nq > 32) return RAG_ERR_INVALID_ARG;
+    if (hipDeviceSynchronize() != hipSuccess) return RAG_ERR_HIP;
+    if (hipMemcpy(out, g_stamps + 2048 * 4, (size_t)nq * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return RAG_ERR_HIP;
     return RAG_OK;
 }
 #endif

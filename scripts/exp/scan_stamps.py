@@ -15,6 +15,8 @@ Q = oracle.synth_rows(4321, 0, 32, d)
 lib = _native.lib()
 lib.rag_debug_scan_stamps.restype = C.c_int
 lib.rag_debug_scan_stamps.argtypes = [C.c_void_p, C.c_int32]
+lib.rag_debug_resolve_stamps.restype = C.c_int
+lib.rag_debug_resolve_stamps.argtypes = [C.c_void_p, C.c_int32]
 idx = FlatIndex(d); idx.add_synthetic(rows, 1234)
 for mode in ("one-pass", "two-stage"):
     if mode == "two-stage":
@@ -42,5 +44,13 @@ for mode in ("one-pass", "two-stage"):
     left = n_tiles - (n_tiles // 2048) * 2048
     if 0 < left < 256:
         print(f"  loop-done, workgroups with a leftover tile (b < {left}): {done[:left].mean():.1f}; without: {done[left:].mean():.1f}")
+    if mode == "two-stage":
+        rs = np.zeros((32, 8), dtype=np.uint64)
+        assert lib.rag_debug_resolve_stamps(rs.ctypes.data, 32) == 0
+        rt = (rs[:, :6].astype(np.int64) - int(st[:, 0].min())) / 100.0
+        names_r = ["entry", "staged", "k-th key", "band", "scored", "exit"]
+        print("  resolve kernel (us after the scan's first entry; median over 32 workgroups): " +
+              ", ".join(f"{nm} {np.median(rt[:, i]):.1f}" for i, nm in enumerate(names_r)))
+        print("  resolve phases (median us): " + ", ".join(f"{names_r[i+1]} {np.median(rt[:, i+1]-rt[:, i]):.2f}" for i in range(5)))
     q = np.argsort(done)
     print("  ten latest workgroups:", q[-10:].tolist(), " ten earliest:", q[:10].tolist(), flush=True)
