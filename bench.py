@@ -173,13 +173,29 @@ def main() -> None:
     out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
     fin = {}
 
+    # N > 1: two batches in flight (submit / collect).  A rank's two-stage search defers its fp32 fallback: the
+    # "not final" word rides in the all-gather and the host reads it back one batch later, while the next batch
+    # is already queued on the GPU (sharded.py); every batch is collected — checked, repeated if flagged —
+    # inside the timed region (barrier() drains).
+    pend: list = []
+
+    def submit(q) -> None:
+        pend.append(sharded.submit(q, k))
+        if len(pend) > 1:
+            fin["s"], fin["i"] = sharded.collect(pend.pop(0))
+
+    def drain() -> None:
+        while pend:
+            fin["s"], fin["i"] = sharded.collect(pend.pop(0))
+
     def step() -> None:
         if sharded is None:
             index.search_device(Q.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
         else:
-            fin["s"], fin["i"] = sharded.search_tensors(Q, k)
+            submit(Q)
 
     def barrier() -> None:
+        drain()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -207,6 +223,7 @@ def main() -> None:
         barrier()
         t1 = time.perf_counter()
         step()
+        drain()
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
     p50_ms = float(np.median(lat) * 1e3) if lat else None
@@ -219,7 +236,7 @@ def main() -> None:
     # stream sync) per step; p50 over the steps.  PCIe-inclusive, so never `value`.
     def host_leg() -> dict | None:
         if world > 1:
-            return None
+            return serving_leg()
         Qh = np.ascontiguousarray(Q.cpu().numpy())
         for _ in range(max(2, args.warmup)):
             index.search(Qh, k)
@@ -236,7 +253,41 @@ def main() -> None:
                 "identical_to_device_path": bool(np.array_equal(Ih, res_i) and np.array_equal(Dh.view(np.uint32), res_s.view(np.uint32))),
                 "path": f"rag_index_search: host queries ({B * d * 4} B H2D) -> results on host ({12 * B * k} B D2H), one sync per batch"}
 
+    # N > 1: the step the PRODUCT serves (FAISSStore.search on rank 0 -> ShardedFlatIndex.leader_search, the other
+    # ranks in follower_loop): host queries -> one pinned message -> one upload -> ONE broadcast -> local search
+    # on the query device pointer inside the message -> all-gather -> merge -> ids, scores and the flag word
+    # back in one copy.  Never `value` (PCIe- and host-inclusive).
+    def serving_leg() -> dict | None:
+        Qh = np.ascontiguousarray(Q.cpu().numpy())
+        barrier()
+        out = None
+        if rank == 0:
+            for _ in range(max(2, args.warmup)):
+                sharded.leader_search(Qh, k)
+            per = []
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                t1 = time.perf_counter()
+                Dh, Ih = sharded.leader_search(Qh, k)
+                per.append(time.perf_counter() - t1)
+            el = time.perf_counter() - t0
+            sharded.shutdown()
+            out = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                   "p50_latency_ms": float(np.median(per) * 1e3), "p95_latency_ms": float(np.percentile(per, 95) * 1e3),
+                   "steps": args.steps, "_D": Dh, "_I": Ih,
+                   "path": f"ShardedFlatIndex.leader_search on rank 0, {world - 1} follower rank(s) in follower_loop: one "
+                           f"{sharded._msg_bytes} B message per batch (one H2D, one broadcast), local search, one "
+                           f"all-gather of {world} x {12 * B * k + 8} B, device merge, one D2H of ids + scores + flag"}
+        else:
+            sharded.follower_loop()
+        barrier()
+        return out
+
     host_one_pass = host_leg()
+    if host_one_pass is not None and "_I" in host_one_pass:
+        Dh, Ih = host_one_pass.pop("_D"), host_one_pass.pop("_I")
+        host_one_pass["identical_to_device_path"] = bool(np.array_equal(Ih, res_i) and
+                                                         np.array_equal(Dh.view(np.uint32), res_s.view(np.uint32)))
 
     # Extra leg (reported beside the headline, never as `value`): the same step with the query encoder
     # in front — token ids resident in HBM -> bge-base-architecture encoder (fp32 MFMA, seeded random
@@ -256,15 +307,18 @@ def main() -> None:
         seqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in lens]
         ids_np, _, cu_np = pack_sequences(seqs)
         ids_t, cu_t = torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda()
-        Qe = torch.empty((B, d), dtype=torch.float32, device="cuda")
+        Qe2 = [torch.empty((B, d), dtype=torch.float32, device="cuda") for _ in range(3)]
+        enc_n = [0]
 
         def enc_step() -> None:
+            Qe = Qe2[enc_n[0] % 3]   # a batch's embeddings stay put until that batch has been collected
+            enc_n[0] += 1
             model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
                                  _native.BERT_OUT_CLS, True, Qe.data_ptr(), sptr)
             if sharded is None:
                 index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
             else:
-                fin["s"], fin["i"] = sharded.search_tensors(Qe, k)
+                submit(Qe)
 
         for _ in range(max(2, args.warmup)):
             enc_step()
@@ -317,7 +371,14 @@ def main() -> None:
                 torch.cuda.synchronize()
                 lat2.append(time.perf_counter() - t1)
             st = index.screen_stats()
+            step(); barrier()
+            r2_s0 = (fin["s"] if world > 1 else out_s).cpu().numpy()
+            r2_i0 = (fin["i"] if world > 1 else out_i).cpu().numpy()
             host_two_stage = host_leg()
+            if host_two_stage is not None and "_I" in host_two_stage:
+                Dh, Ih = host_two_stage.pop("_D"), host_two_stage.pop("_I")
+                host_two_stage["identical_to_device_path"] = bool(np.array_equal(Ih, r2_i0) and
+                                                                  np.array_equal(Dh.view(np.uint32), r2_s0.view(np.uint32)))
             enc2 = None
             if enc_step is not None:  # text ids -> encoder -> two-stage search
                 for _ in range(2):
@@ -397,7 +458,8 @@ def main() -> None:
                 "workload": f"flat inner-product scan + exact top-{k}: {N} x {d} fp32 rows over {world} GPU(s) "
                             f"({n_local} rows on rank 0), batch {B} precomputed unit-norm query embeddings "
                             "resident in HBM (configs/retrieval_faiss_only.yaml path)"
-                            + ("; per-shard top-k merged by one RCCL all-gather + device merge" if world > 1 else ""),
+                            + ("; per-shard top-k merged by one RCCL all-gather + device merge, two batches in flight"
+                               if world > 1 else ""),
                 "note": "value = the one-pass fp32 scan with queries resident in HBM (the path SURVEY 8(d) defines the "
                         "roofline on); host_submit_to_host_results = the same batches through rag_index_search "
                         "(host queries in, results on host, PCIe inclusive) with its own q/s and p50; "
@@ -427,6 +489,11 @@ def main() -> None:
         }
         if host_one_pass is not None:
             out["host_submit_to_host_results"] = host_one_pass
+        # the step a deployment serves through FAISSStore.search (two-stage by default), next to `value`
+        serving = (two_leg or {}).get("host_submit_to_host_results") or host_one_pass
+        if serving is not None:
+            out["serving_mode"] = dict(serving, search="two-stage exact (FAISSStore default)" if two_leg and
+                                       "host_submit_to_host_results" in two_leg else "one-pass fp32 scan")
         if enc_leg is not None:
             out["with_query_encoder"] = enc_leg
         if two_leg is not None:

@@ -127,6 +127,35 @@ int rag_index_search(rag_index* h, const float* queries_host, int32_t nq, int32_
 int rag_index_search_device(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
                             float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
+/* Same search with the choice the two-stage mode leaves open made by the caller (rag_index_set_screening):
+ *   RAG_SEARCH_DEFAULT         what rag_index_search_device does: a two-stage search enqueues its fp32 fallback
+ *                              behind itself (two launches that switch themselves off on the device when no
+ *                              certificate failed), so the call stays asynchronous and the result is always final;
+ *   RAG_SEARCH_EXACT_ONE_PASS  never screen: the one-pass fp32 scan whatever the index's screening mode;
+ *   RAG_SEARCH_DEFER_FALLBACK  a two-stage search WITHOUT its fallback launches: *flag_dev (a device word of the
+ *                              caller's) is 0 when every query's certificate held — the result is final — and 1
+ *                              when one failed: the caller then repeats the batch with RAG_SEARCH_EXACT_ONE_PASS.
+ *                              The word is written on `stream` by the search's own kernels.  (In the other two
+ *                              modes, and when the search was not screened at all, a non-null flag_dev is set to 0:
+ *                              those results are final.)  This is what the sharded serving step uses: the
+ *                              word travels in each rank's block of the all-gather, and the fp32 scan + a second
+ *                              gather run only when some rank raised it (rag_inference_pipeline_amd/sharded.py).
+ * No counterpart in the reference (faiss IndexFlat has one code path, faiss_store.py:152). */
+#define RAG_SEARCH_DEFAULT 0
+#define RAG_SEARCH_EXACT_ONE_PASS 1
+#define RAG_SEARCH_DEFER_FALLBACK 2
+int rag_index_search_device_ex(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                               float* out_scores_dev, int64_t* out_ids_dev, int32_t mode, uint32_t* flag_dev,
+                               void* stream);
+
+/* Queries in device memory (e.g. left there by rag_bert_encode_to_device on the same stream), results in HOST
+ * memory: the search is enqueued on `stream` behind whatever produced the queries, ids and scores come back
+ * in one read-back each and the call blocks until they are in the output buffers.  This is the hand-off
+ * between the embedder and the index inside one retrieval batch (services/retrieval/api.py:351-390 passes a
+ * host array from one to the other; here the embeddings never leave HBM). */
+int rag_index_search_device_host_out(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                                     float* out_scores, int64_t* out_ids, void* stream);
+
 /* Copy rows [row0, row0+n) back to host memory (parity spot checks at full size). */
 int rag_index_get_rows(rag_index* h, int64_t row0, int64_t n, float* out_rows_host);
 
@@ -177,6 +206,18 @@ int rag_merge_topk_packed_device(int32_t device, int32_t metric, int32_t n_shard
                                  const void* packed_dev, int64_t shard_stride_bytes,
                                  int64_t scores_offset_bytes, float* out_scores_dev, int64_t* out_ids_dev,
                                  void* stream);
+
+/* Same, for blocks that also carry one 32-bit "my result is not final" word each (RAG_SEARCH_DEFER_FALLBACK) at
+ * flag_offset_bytes: *any_flag_dev receives the OR of the n_shards words (written by the merge itself, so the
+ * caller reads ONE word back, not one per rank).  host_mirror (NULL, or pinned host memory the device can write:
+ * hipHostMalloc / torch pin_memory, 8-byte aligned, laid out like ONE shard's block — ids at 0, scores at
+ * scores_offset_bytes, the OR-ed word at flag_offset_bytes) receives the same result from the merge kernel itself:
+ * the batch then needs no read-back copy, only a wait for `stream`. */
+int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                         const void* packed_dev, int64_t shard_stride_bytes,
+                                         int64_t scores_offset_bytes, int64_t flag_offset_bytes,
+                                         float* out_scores_dev, int64_t* out_ids_dev, uint32_t* any_flag_dev,
+                                         void* host_mirror, void* stream);
 
 /* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
 
@@ -255,6 +296,17 @@ int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* 
                             const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
                             int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
                             void* stream);
+
+/* Token ids in HOST memory, result left in DEVICE memory: the hand-off from the embedder to the index inside a
+ * retrieval batch (services/retrieval/api.py:351-390 passes a host array between them; here the embeddings stay
+ * in HBM).  The ids are staged through pinned memory and uploaded on the handle's private stream, the forward
+ * pass is enqueued behind them, and the call returns WITHOUT waiting: *stream_out is that stream (a hipStream_t),
+ * on which the consumer enqueues its own work (rag_index_search_device_host_out) or which it synchronises.
+ * out_dev is caller-owned device memory (nseq x hidden / n_labels floats, by out_kind) and must stay allocated
+ * until that stream has passed this call's work. */
+int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const int32_t* type_ids,
+                               const int32_t* cu_seqlens, int32_t nseq, int32_t out_kind, int32_t normalize,
+                               float* out_dev, void** stream_out);
 
 /* ---- `compressed` document payload (host side) ------------------------------------------- */
 

@@ -31,6 +31,8 @@ RAG_ERR_STATE = 6
 METRIC_INNER_PRODUCT = 0
 METRIC_L2 = 1
 
+SEARCH_DEFAULT, SEARCH_EXACT_ONE_PASS, SEARCH_DEFER_FALLBACK = 0, 1, 2  # include/rag_amd.h RAG_SEARCH_*
+
 # rag_bert_config (include/rag_amd.h)
 ACT_GELU, ACT_GELU_TANH, ACT_RELU = 1, 2, 3
 HEAD_NONE, HEAD_BERT, HEAD_ROBERTA = 0, 1, 2
@@ -111,6 +113,8 @@ def _declare(lib: C.CDLL) -> None:
         "rag_index_set_id_offset": (C.c_int, [vp, C.c_int64]),
         "rag_index_search": (C.c_int, [vp, f32p, C.c_int32, C.c_int32, f32p, i64p]),
         "rag_index_search_device": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp, vp]),
+        "rag_index_search_device_ex": (C.c_int, [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp]),
+        "rag_index_search_device_host_out": (C.c_int, [vp, vp, C.c_int32, C.c_int32, f32p, i64p, vp]),
         "rag_index_get_rows": (C.c_int, [vp, C.c_int64, C.c_int64, f32p]),
         "rag_index_profile_enable": (C.c_int, [vp, C.c_int32]),
         "rag_index_profile": (C.c_int, [vp, C.POINTER(C.c_double), i64p, C.c_int32]),
@@ -125,11 +129,15 @@ def _declare(lib: C.CDLL) -> None:
                                             vp, vp, vp, vp, vp]),
         "rag_merge_topk_packed_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                    vp, C.c_int64, C.c_int64, vp, vp, vp]),
+        "rag_merge_topk_packed_flagged_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                           vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]),
         "rag_bert_weight_count": (C.c_int32, [C.POINTER(BertConfigStruct)]),
         "rag_bert_create": (C.c_int, [C.POINTER(BertConfigStruct), C.POINTER(vp), C.c_int32, C.c_int32,
                                       C.POINTER(vp)]),
         "rag_bert_destroy": (C.c_int, [vp]),
         "rag_bert_forward": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, f32p]),
+        "rag_bert_forward_to_device": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, vp,
+                                                 C.POINTER(vp)]),
         "rag_bert_forward_device": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, vp, vp]),
     }

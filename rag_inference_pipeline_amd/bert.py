@@ -311,6 +311,28 @@ class BertModel:
             int(total_tokens), int(max_seq_len), int(out_kind), 1 if normalize else 0, C.c_void_p(out_ptr),
             C.c_void_p(stream)))
 
+    def embed_to_device(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None,
+                        normalize: bool = True, pooling: str | None = None):
+        """embed() without the read-back: token ids go up, the forward pass is enqueued on the model's private
+        stream and the call returns a DeviceEmbeddings handle at once (rag_bert_forward_to_device)."""
+        import torch
+
+        from .device_embeddings import DeviceEmbeddings
+
+        if not self._h:
+            raise RuntimeError("BertModel is closed")
+        ids, types, cu = pack_sequences(seqs, type_seqs)
+        kind = _native.BERT_OUT_CLS if (pooling or self.cfg.pooling) == "cls" else _native.BERT_OUT_MEAN
+        i32p = C.POINTER(C.c_int32)
+        out = torch.empty((len(seqs), self.cfg.hidden), dtype=torch.float32, device=torch.device("cuda", self.device))
+        stream = C.c_void_p()
+        _native.check(self._lib.rag_bert_forward_to_device(
+            self._h, ids.ctypes.data_as(i32p), types.ctypes.data_as(i32p) if types is not None else None,
+            cu.ctypes.data_as(i32p), len(seqs), kind, 1 if normalize else 0, C.c_void_p(out.data_ptr()),
+            C.byref(stream)))
+        # (a closed model has waited for the device: nothing of its can still be writing to `out`)
+        return DeviceEmbeddings(out, int(stream.value or 0), self.device, producer_alive=lambda: bool(self._h))
+
     def embed(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None,
               normalize: bool = True, pooling: str | None = None) -> np.ndarray:
         """(n, hidden) sentence embeddings: pooled last hidden state, L2-normalised by default."""

@@ -76,6 +76,22 @@ class EmbeddingGenerator:
             out[lo:hi] = self._model.embed(ids[lo:hi], types[lo:hi], normalize=True)
         return out
 
+    def encode_device(self, texts: list[str]):
+        """encode() whose result stays in HBM: a DeviceEmbeddings handle (pointer + producer stream) that
+        FAISSStore.search takes as it is, so a retrieval batch reads back its ids and scores and nothing else.
+        Same error contract as encode(); batches beyond the per-pass token budget and the cached mode (keyed
+        on host values) go through encode()."""
+        if not self._is_loaded or self._model is None:
+            raise RuntimeError("Model not loaded. Call load() first.")
+        if not texts:
+            raise ValueError("Cannot encode empty text list")
+        if not getattr(self.settings, "disable_cache_for_profiling", True):
+            return self.encode(texts)
+        ids, types = self._tokenizer.encode_batch(list(texts), self._max_len)
+        if sum(len(s) for s in ids) > _MAX_TOKENS_PER_PASS:
+            return self.encode(texts)
+        return self._model.embed_to_device(ids, types, normalize=True)
+
     def encode(self, texts: list[str]) -> np.ndarray:
         if not self._is_loaded or self._model is None:
             raise RuntimeError("Model not loaded. Call load() first.")

@@ -28,6 +28,7 @@ import numpy as np
 
 from .. import _native, index_io
 from ..config import PipelineSettings, resolve_gpu_device
+from ..device_embeddings import DeviceEmbeddings
 
 logger = logging.getLogger(__name__)
 
@@ -37,6 +38,8 @@ _TWO_STAGE_MAX_D = 2048    # rag_index_set_screening covers d <= 2048
 
 class FAISSStore:
     """Exhaustive (flat) vector index resident on one MI355X."""
+
+    accepts_device_embeddings = True  # search() takes EmbeddingGenerator.encode_device's handle
 
     def __init__(self, settings: PipelineSettings) -> None:
         self.settings = settings
@@ -86,7 +89,8 @@ class FAISSStore:
             if world > 1:
                 from ..sharded import ShardedFlatIndex
 
-                self._sharded = ShardedFlatIndex(index, metric, device=device)
+                self._sharded = ShardedFlatIndex(index, metric, device=device, dim=d,
+                                                 max_batch=max(1, int(getattr(self.settings, "retrieval_batch_size", 32))))
             self._is_loaded = True
             logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (rows %d..%d on this rank)",
                         n, d, row_lo, row_hi)
@@ -111,9 +115,20 @@ class FAISSStore:
         if embeddings.shape[1] != self.settings.faiss_dim:
             raise ValueError(
                 f"Embedding dimension mismatch: expected {self.settings.faiss_dim}, got {embeddings.shape[1]}")
-        embeddings = embeddings.astype("float32")
         logger.debug("Searching FAISS index with %d queries, k=%d", embeddings.shape[0], k)
         try:
+            if isinstance(embeddings, DeviceEmbeddings):
+                # the embedder's result never left HBM: the search is enqueued behind it on its stream and only
+                # ids and scores come back (a sharded deployment ships host bytes in its request message)
+                if self._sharded is None and embeddings.device == self._index.device:
+                    res = self._index.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, embeddings.stream)
+                    embeddings.settled()  # the call has waited for the stream
+                    return res
+                embeddings = embeddings.numpy()
+            # the reference converts unconditionally (faiss_store.py:147); a C-contiguous fp32 array is already
+            # what the C ABI reads, so it is passed as it is (search never writes to it)
+            if not (isinstance(embeddings, np.ndarray) and embeddings.dtype == np.float32 and embeddings.flags.c_contiguous):
+                embeddings = np.ascontiguousarray(embeddings, dtype=np.float32)
             if self._sharded is not None:
                 return self._sharded.leader_search(embeddings, k)
             return self._index.search(embeddings, k)

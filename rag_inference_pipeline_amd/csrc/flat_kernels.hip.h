@@ -168,6 +168,14 @@ struct ScanParams {
                            // bound covers)
     uint32_t* wg_lossy;    // [kQT][grid] = epoch when THIS workgroup could not hold a query's band and fell back to
                            // its best k for that query (null: not recorded — sample pass)
+    uint32_t* flag_clear;  // null, or the caller's "a certificate failed" word (RAG_SEARCH_DEFER_FALLBACK): workgroup 0
+                           // zeroes it here, one kernel boundary ahead of the resolve kernel that may set it
+    // dynamic deal of the last rounds ("tile walk" in the kernel).  dyn_ctr == null: everything is dealt statically.
+    uint32_t* dyn_ctr;       // this launch's ticket counter (0 at launch)
+    uint32_t* dyn_ctr_next;  // the next launch's counter: workgroup 0 zeroes it (launches of an index are stream-ordered)
+    int dyn_tile0;           // first tile of the dynamic region = n_full * grid * NW
+    int n_dyn_groups;        // tickets [0, n_dyn_groups): whole NW-tile groups; then n_singles tickets of one tile each
+    int n_singles;
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
 #endif
@@ -180,9 +188,9 @@ struct ScanParams {
 #endif
 
 // LDS layout: [Q fragments d8*128 B][keys 32*C*8 B][cnt 32 u32][thr 32 f32][flag 4 u32][margin 32 f32]
-//             [query scale 32 f32][1 / (query scale * corpus scale) 32 f32]
+//             [query scale 32 f32][1 / (query scale * corpus scale) 32 f32][ticket, iteration u32 + pad]
 __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = columns held in LDS (one chunk)
-    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4 + 2 * kQT * 4;
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4 + 2 * kQT * 4 + 16;  // + ticket word
 }
 
 // NW = waves per workgroup (NW/4 per SIMD), E = buffer capacity / 64, D = register ring depth
@@ -195,8 +203,12 @@ __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = colum
 //        running k-th best, which is what makes the exact second stage a proof rather than a guess.
 template <int NW, int E, int D, bool L2, int P>
 __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) {
+    // the screening prologue reduces ||q||^2 and max|q| through 2 * NW = 16 partials per query
+    static_assert(P != 1 || NW == 8, "the screening pass (P == 1) is written for 8 waves per workgroup");
+    if (p.dyn_ctr_next && blockIdx.x == 0 && threadIdx.x == 0) *p.dyn_ctr_next = 0u;  // also by a switched-off launch
     if (p.enable && *p.enable != p.epoch) return;  // launch-uniform
     RAGK_STAMP(0);
+    if (P == 1 && p.flag_clear && blockIdx.x == 0 && threadIdx.x == 0) *p.flag_clear = 0u;
     constexpr int C = 64 * E;
     constexpr int kScanWaves = NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,6 +226,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     float* mrg = reinterpret_cast<float*>(flag + 4);
     float* qsc_s = mrg + kQT;   // P == 1: per-query scales, computed in the prologue
     float* uns_s = qsc_s + kQT;
+    // dynamic deal: tickw[0] = ticket, tickw[1] = the iteration it is for.  Written in that order by one thread and
+    // read in the opposite order (LDS operations of a wave execute in order): a reader that sees the iteration
+    // number sees its ticket
+    volatile uint32_t* tickw = reinterpret_cast<volatile uint32_t*>(uns_s + kQT);
 
     // ---- tile walk.  Rounds 0 .. n_full-1: wave w of workgroup b takes tile (b NW + w) + round * grid * NW
     // (the 8 waves of a workgroup read 8 consecutive tiles).  The last, partial round hands its leftover
@@ -221,6 +237,18 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // on an otherwise idle CU costs a third of a full round, and every CU gets one before any gets two.
     // (With whole 8-tile groups in the last round, 1.25M rows = 19.07 rounds ran as 20: 19 CUs streamed
     // a 20th group while 237 idled — 5 % of the scan.)
+    //
+    // Dynamic deal (p.dyn_ctr != null; long scans only).  CUs do not stream at the same rate: dealt statically,
+    // the workgroups of a 1.25M-row scan finish 20-40 us apart (phase stamps, DESIGN "fixed cost") and the chip
+    // waits for the slowest.  So only rounds 0 .. n_full-1 are static here and the rest of the corpus — two to
+    // three rounds' worth — goes out by TICKET from one global counter: first whole NW-tile groups (the quantum
+    // at which a CU streams at full rate), then n_singles single tiles, one per ticket, done by a lone wave (a
+    // third of a group's time: they fill the gaps the groups leave).  A workgroup draws the ticket of iteration
+    // it + 1 at the top of iteration it (thread 0; one returning atomic, a tile time before its result is needed)
+    // and publishes it through an LDS word {iteration, ticket} that every wave reads before it prefetches the next
+    // tile's first rows; a ticket beyond the last single tile ends the workgroup's walk — uniformly, so the
+    // per-iteration barriers stay matched.  Which workgroup scans which tile does not change the result: the
+    // merge takes the exact top-k of the union of the workgroups' lists.
     const long long last_row = p.n_rows - 1;
     const long long tile_rows = (long long)kTileRows * p.tile_step;  // distance between consecutive tiles' first rows
     const int tiles_per_iter = gridDim.x * kScanWaves;
@@ -416,6 +444,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         }
     }
     if (tid < 4) flag[tid] = 0;
+    if (tid == 0) tickw[1] = 0u;  // no iteration has this number: tickets are for iterations >= n_full >= 4
     __syncthreads();
     RAGK_STAMP(1);
 
@@ -428,11 +457,15 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // the slot of pass seq + 2, so a wave that has already left a pass never races a wave that is
     // still reading that pass's flag.
     uint32_t seq = 0;
-    for (int it = 0; it < p.n_iters; ++it) {
-        tile = tile_of(it);
+    const bool dyn = p.dyn_ctr != nullptr;  // kernel-uniform; then n_iters == n_full: the static rounds
+    bool more = p.n_iters > 0;              // workgroup-uniform: iteration `it` exists
+    for (int it = 0; more; ++it) {
         const bool active = tile < p.n_tiles;  // wave-uniform
-        const int tnext = it + 1 < p.n_iters ? tile_of(it + 1) : p.n_tiles;
-        const float* pn = row_ptr(tnext < p.n_tiles ? tnext : p.n_tiles - 1);
+        if (dyn && it + 1 >= p.n_iters && tid == 0) {  // the ticket of iteration it + 1
+            const uint32_t g = atomicAdd(p.dyn_ctr, 1u);
+            tickw[0] = g;
+            tickw[1] = (uint32_t)(it + 1);
+        }
 
         f32x16 acc;
 #pragma unroll
@@ -472,6 +505,23 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // the next tile: static rounds by formula, later ones by the ticket drawn at the top of this iteration
+        int tnext = p.n_tiles;
+        bool more_next;
+        if (!dyn || it + 1 < p.n_iters) {
+            more_next = it + 1 < p.n_iters;
+            if (more_next) tnext = tile_of(it + 1);
+        } else {
+            while (tickw[1] != (uint32_t)(it + 1)) {
+            }
+            const int g = __builtin_amdgcn_readfirstlane((int)tickw[0]);
+            more_next = g < p.n_dyn_groups + p.n_singles;
+            if (g < p.n_dyn_groups)
+                tnext = p.dyn_tile0 + g * kScanWaves + wave;
+            else if (more_next && wave == 0)
+                tnext = p.dyn_tile0 + p.n_dyn_groups * kScanWaves + (g - p.n_dyn_groups);
+        }
+        const float* pn = row_ptr(tnext < p.n_tiles ? tnext : p.n_tiles - 1);
         // last D steps: refill the ring from the next tile
         {
             const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
@@ -501,6 +551,8 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                 for (int i = 0; i < 16; ++i)
                     p.acc_io[((size_t)tile * kTileRows + (i & 3) + 8 * (i >> 2) + 4 * h) * kQT + r] = acc[i];
             }
+            tile = tnext;
+            more = more_next;
             continue;
         }
 
@@ -702,6 +754,8 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
             }
         }
         if (it == 0) RAGK_STAMP(2);
+        tile = tnext;
+        more = more_next;
     }
 
     if (p.acc_out) return;
@@ -806,6 +860,17 @@ struct MergeOut {
     int from_shards;     // keys carry (-distance, id) of already finished results
     const uint32_t* qmask;  // null, or [nq] words: only queries whose word equals `epoch` are written (fallback path)
     uint32_t epoch;
+    // shard merge only: every shard's block of the gathered buffer carries one "my result is not final" word
+    // (RAG_SEARCH_DEFER_FALLBACK); query 0's workgroup ORs them into *any_flag (null: no flags)
+    const uint32_t* flags;   // word of shard 0
+    long long flag_stride;   // uint32 words between consecutive shards' flag words
+    int n_flags;
+    uint32_t* any_flag;
+    // optional mirror of the result in pinned HOST memory (same [nq][out_stride] layout + the OR-ed flag word): the
+    // merge writes it itself — posted stores, a few KB — so the batch needs no read-back copy behind the kernel
+    float* scores_host;
+    long long* ids_host;
+    uint32_t* any_flag_host;
 };
 
 // Wave-wide 64-bit max on the DPP cross-lane paths (quad permutes, row mirrors, row broadcasts): a
@@ -922,6 +987,12 @@ __global__ __launch_bounds__(64 * WAVES) void tournament_merge_kernel(const Src 
     __shared__ u64 wmax[2][4];
     const int q = blockIdx.x, tid = threadIdx.x;
     if (out.qmask && out.qmask[q] != out.epoch) return;  // workgroup-uniform
+    if (out.any_flag && q == 0 && tid == 0) {
+        uint32_t any = 0u;
+        for (int g = 0; g < out.n_flags; ++g) any |= out.flags[(size_t)g * out.flag_stride];
+        *out.any_flag = any;
+        if (out.any_flag_host) *out.any_flag_host = any;
+    }
     stage_heads<Src, 64 * WAVES>(src, q, n_lists, look, ahead, tid);
     __syncthreads();
     tournament_rounds<Src, OWN, WAVES, false>(src, q, n_lists, k, k, look, ahead, wmax, tid, [&](int round, u64 bm) {
@@ -945,6 +1016,10 @@ __global__ __launch_bounds__(64 * WAVES) void tournament_merge_kernel(const Src 
         }
         out.scores[(size_t)q * out.out_stride + round] = s;
         out.ids[(size_t)q * out.out_stride + round] = id;
+        if (out.scores_host) {
+            out.scores_host[(size_t)q * out.out_stride + round] = s;
+            out.ids_host[(size_t)q * out.out_stride + round] = id;
+        }
         if (out.last_key && round == k - 1) out.last_key[q] = bm;
     });
 }
@@ -1092,6 +1167,7 @@ struct ResolveParams {
     ScreenCounters* ctr;
     float* out_s;            // [nq][k]
     long long* out_i;
+    uint32_t* flag_out;      // null, or the caller's word (RAG_SEARCH_DEFER_FALLBACK): set to 1 when a certificate failed
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [nq][8] phase stamps
 #endif
@@ -1287,6 +1363,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
         if (!ok) {
             p.qs->fallback[q] = p.epoch;
             p.qs->any_fallback = p.epoch;
+            if (p.flag_out) *p.flag_out = 1u;
             atomicAdd(&p.ctr->fallbacks, 1ull);
         } else if (eps > 0.f) {
             atomicMax(&p.ctr->max_err_ratio_bits, __float_as_uint(worst / eps));

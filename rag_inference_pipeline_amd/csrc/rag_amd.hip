@@ -91,11 +91,6 @@ ScanFn screen_fn(int cap, int ring, bool l2) {
         default: return screen_fn_cap<4>(ring, l2);
     }
 }
-#ifdef RAGK_TUNING
-ScanFn screen_fn12(bool l2) {  // experiment: 12 waves, cap 64, ring 8
-    return l2 ? (ScanFn)ragk::scan_topk_kernel<12, 1, 8, true, 1> : (ScanFn)ragk::scan_topk_kernel<12, 1, 8, false, 1>;
-}
-#endif
 template <int NW, int E>
 ScanFn scan_fn_ring(int ring, bool l2) {
     switch (ring) {
@@ -203,6 +198,13 @@ struct rag_index {
     ragk::ScreenCounters* sctr = nullptr;
     uint32_t screen_epoch = 0;   // id of the last two-stage search (ragk::ScreenQueryState flags are epoch-valued)
     uint32_t* wg_lossy = nullptr;  // kQT x kWgLossyLists epoch-valued words: (query, workgroup) pairs that gave up a band
+
+    // dynamic deal of a long scan's last rounds: one ticket counter per launch out of a ring — launch i zeroes the
+    // counter of launch i + 1 (every scan launch of an index is stream-ordered behind the previous one)
+    uint32_t* dyn_ctrs = nullptr;
+    unsigned dyn_slot = 0;
+    int dyn_rounds = 2;          // rounds' worth of tiles dealt by ticket (0: static deal only); RAG_AMD_SCAN_DYN_ROUNDS
+    int dyn_singles_per_wg = 0;  // single-tile tickets per workgroup at the very end; RAG_AMD_SCAN_DYN_SINGLES
 
     // sample pass (starting thresholds for k >= kSampleMinK)
     ragk::u64* sample_heads = nullptr;  // kQT x kSampleLists workgroup maxima
@@ -356,6 +358,36 @@ int ensure_search_ws(rag_index* h, int nq_total, int k, int grid) {
     return RAG_OK;
 }
 
+// Dynamic deal of the last rounds of a long scan (flat_kernels.hip.h "tile walk"): fills the dyn_* fields of `sp`
+// and shortens its static part to n_full - dyn_rounds rounds.  Short scans (fewer than kDynMinRounds full rounds)
+// and chunked scans keep the static deal.
+constexpr int kDynMinRounds = 6;
+constexpr int kDynSlots = 64;
+int setup_dynamic_deal(rag_index* h, ragk::ScanParams& sp, int grid, int waves) {
+    sp.dyn_ctr = sp.dyn_ctr_next = nullptr;
+    sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
+    if (h->dyn_rounds <= 0 || sp.n_full < kDynMinRounds || waves != 8) return RAG_OK;
+    if (!h->dyn_ctrs) {
+        int rc = dev_alloc(&h->dyn_ctrs, (size_t)kDynSlots);
+        if (rc) return rc;
+        HIP_TRY(hipMemset(h->dyn_ctrs, 0, kDynSlots * sizeof(uint32_t)));
+    }
+    const int n_static = std::max(4, sp.n_full - h->dyn_rounds);  // the warm start and the first sorts stay in lockstep
+    const int tile0 = n_static * grid * waves;
+    const int n_dyn_tiles = sp.n_tiles - tile0;
+    const int want_singles = std::min(n_dyn_tiles, grid * std::max(0, h->dyn_singles_per_wg));
+    const int n_groups = (n_dyn_tiles - want_singles) / waves;
+    sp.dyn_ctr = h->dyn_ctrs + h->dyn_slot % kDynSlots;
+    sp.dyn_ctr_next = h->dyn_ctrs + (h->dyn_slot + 1) % kDynSlots;
+    ++h->dyn_slot;
+    sp.dyn_tile0 = tile0;
+    sp.n_dyn_groups = n_groups;
+    sp.n_singles = n_dyn_tiles - n_groups * waves;
+    sp.n_full = n_static;
+    sp.n_iters = n_static;
+    return RAG_OK;
+}
+
 // Sample pass (flat_kernels.hip.h, "sample pass -> starting thresholds"): the scan kernel with k = 1 over
 // kSampleLists * 8 tiles spread through the corpus, then the k-th largest workgroup maximum per query
 // into h->thr_keys.  `base` is the ScanParams of the real scan (same corpus view, metric, ceiling).
@@ -384,6 +416,8 @@ int run_sample_pass(rag_index* h, const ragk::ScanParams& base, ScanFn fn, size_
 #endif
     if (ss.lossy) ss.lossy = h->sq->sample_lossy;
     ss.wg_lossy = nullptr;  // the sample pass's lists only seed thresholds
+    ss.flag_clear = nullptr;
+    ss.dyn_ctr = ss.dyn_ctr_next = nullptr;
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipLaunchKernelGGL(fn, dim3(lists), dim3(8 * 64), lds, st, ss);
     HIP_TRY(hipGetLastError());
@@ -461,6 +495,9 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.margin_out = nullptr;
         sp.lossy = nullptr;
         sp.wg_lossy = nullptr;
+        sp.flag_clear = nullptr;
+        sp.dyn_ctr = sp.dyn_ctr_next = nullptr;
+        sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
 #ifdef RAGK_STAMPS
         if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
         sp.stamps = enable ? nullptr : g_stamps;
@@ -492,7 +529,8 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
             if (ring_ok(S, rg)) ring = rg;
         }
 #endif
-        const ScanParams sp = make_params(col0, dc8);
+        ScanParams sp = make_params(col0, dc8);
+        if (!chunked && (rc = setup_dynamic_deal(h, sp, grid, waves))) return rc;
         ScanFn fn = scan_fn(waves, cap, ring, l2);
         const size_t lds = scan_lds_bytes(dc8, cap);
         if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
@@ -555,8 +593,10 @@ int screen_capacity(int d64, int k) {
 // `deferred_epoch` (host-pointer entry point, one block): do not enqueue the fallback launches; hand back the
 // search's epoch so the caller, who synchronises anyway, can read `any_fallback` with the results and run the
 // fallback only when a certificate failed (two launches, 8.5 us, saved on every batch that needs none).
+// `flag_dev` (RAG_SEARCH_DEFER_FALLBACK): no fallback launches either; the resolve kernel sets *flag_dev = 1 when
+// a certificate failed, and with `flag_clear` this block's scan zeroes the word first (the first block of a search).
 int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* os, long long* oi, hipStream_t st,
-                          uint32_t* deferred_epoch = nullptr) {
+                          uint32_t* deferred_epoch = nullptr, uint32_t* flag_dev = nullptr, bool flag_clear = false) {
     using namespace ragk;
     // candidate slots per query: always the most the resolve kernel's final sort takes (empty slots cost
     // nothing: candidates are packed at the front of an LDS list and scored 32 at a time), so a dense
@@ -564,10 +604,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     const int kp = 240;
     const int cap = screen_capacity(h->d64, k);
     const bool l2 = h->metric == RAG_METRIC_L2;
-    int waves = 8;
-#ifdef RAGK_TUNING
-    if (env_int("RAG_AMD_SCREEN_WAVES", 0) == 12 && cap == 64 && (h->d64 / 16) % 8 == 0) waves = 12;
-#endif
+    constexpr int waves = 8;  // the screening prologue is written for 8 waves (static_assert in the kernel)
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
     const int n_tiles = (int)n_tiles_ll;
     int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + waves - 1) / waves);
@@ -622,6 +659,9 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.margin_out = h->sq->margin;
     sp.lossy = h->sq->lossy;
     sp.wg_lossy = h->wg_lossy;
+    sp.flag_clear = flag_clear ? flag_dev : nullptr;
+    sp.dyn_ctr = sp.dyn_ctr_next = nullptr;
+    sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
 #ifdef RAGK_STAMPS
     if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
     sp.stamps = g_stamps;
@@ -632,10 +672,8 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         if (rc) return rc;
         sp.thr_key = h->thr_keys;  // allocated by the first sample pass
     }
+    if ((rc = setup_dynamic_deal(h, sp, grid, waves))) return rc;   // after the sample pass took its copy of sp
     ScanFn fn = screen_fn(cap, S % 8 == 0 ? 8 : 4, l2);
-#ifdef RAGK_TUNING
-    if (waves == 12) fn = screen_fn12(l2);
-#endif
     const size_t lds = scan_lds_bytes(h->d64 / 2, cap);
     if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -675,6 +713,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         rp.ctr = h->sctr;
         rp.out_s = os;
         rp.out_i = oi;
+        rp.flag_out = flag_dev;
 #ifdef RAGK_STAMPS
         rp.stamps = g_stamps ? g_stamps + 2048 * 4 : nullptr;  // second half of the stamp buffer
 #endif
@@ -697,11 +736,13 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         *deferred_epoch = epoch;
         return RAG_OK;
     }
+    if (flag_dev) return RAG_OK;  // the caller reads the word and re-runs the batch through the fp32 scan if it is set
     return search_exact_block(h, qp, nb, k, os, oi, st, &h->sq->any_fallback, h->sq->fallback, epoch);
 }
 
 int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float* out_s, long long* out_i,
-                         hipStream_t st, uint32_t* deferred_epoch = nullptr) {
+                         hipStream_t st, uint32_t* deferred_epoch = nullptr, int mode = RAG_SEARCH_DEFAULT,
+                         uint32_t* flag_dev = nullptr) {
     if (deferred_epoch) *deferred_epoch = 0;  // 0: nothing was deferred
     if (h->ws_used && h->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
     struct Mark {  // record the workspace hand-over point on every exit path
@@ -714,24 +755,39 @@ int search_device_locked(rag_index* h, const float* q_dev, int nq, int k, float*
             }
         }
     } mark{h, st};
+    const bool screened = h->n > 0 && mode != RAG_SEARCH_EXACT_ONE_PASS && h->screen_on && h->screen_valid &&
+                          k <= kScreenMaxK && h->d64 <= kScreenMaxD64 && screen_capacity(h->d64, k) > 0;
+    const bool flagged = mode == RAG_SEARCH_DEFER_FALLBACK && flag_dev && screened;
+    // the caller's word is always written: a search that defers nothing (one-pass, or a two-stage search with its
+    // fallback enqueued) is final
+    if (flag_dev && !flagged) HIP_TRY(hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), st));
     if (h->n == 0) {
         const int total = nq * k;
         ragk::fill_neutral_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(out_s, out_i, total, h->metric);
         HIP_TRY(hipGetLastError());
         return RAG_OK;
     }
-    const bool screened = h->screen_on && h->screen_valid && k <= kScreenMaxK && h->d64 <= kScreenMaxD64 &&
-                          screen_capacity(h->d64, k) > 0;
     for (int q0 = 0; q0 < nq; q0 += ragk::kQT) {
         const int nb = std::min(ragk::kQT, nq - q0);
         const float* qp = q_dev + (size_t)q0 * h->d;
         float* os = out_s + (size_t)q0 * k;
         long long* oi = out_i + (size_t)q0 * k;
         const bool defer = deferred_epoch && screened && nq <= ragk::kQT;  // one block: its flags stay valid until read
-        int rc = screened ? search_screened_block(h, qp, nb, k, os, oi, st, defer ? deferred_epoch : nullptr)
+        int rc = screened ? search_screened_block(h, qp, nb, k, os, oi, st, defer ? deferred_epoch : nullptr,
+                                                  flagged ? flag_dev : nullptr, q0 == 0)
                           : search_exact_block(h, qp, nb, k, os, oi, st);
         if (rc) return rc;
     }
+    return RAG_OK;
+}
+
+// Row count and global-id range after adding n rows; the caller holds h->mu (a concurrent set_id_offset and add
+// could otherwise each pass their own check and together wrap the 32-bit ids of the shard merge).
+int check_add_range(const rag_index* h, long long n) {
+    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
+    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
+        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
+                    h->id_offset, (long long)(h->n + n));
     return RAG_OK;
 }
 
@@ -782,6 +838,8 @@ extern "C" int rag_index_create(int32_t d, int32_t metric, int32_t device, rag_i
         return fail(RAG_ERR_HIP, "hipGetDeviceProperties failed");
     }
     h->n_cus = prop.multiProcessorCount;
+    h->dyn_rounds = std::max(0, std::min(1 << 20, env_int("RAG_AMD_SCAN_DYN_ROUNDS", h->dyn_rounds)));
+    h->dyn_singles_per_wg = std::max(0, std::min(16, env_int("RAG_AMD_SCAN_DYN_SINGLES", h->dyn_singles_per_wg)));
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming) != hipSuccess) {
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -803,7 +861,7 @@ extern "C" int rag_index_destroy(rag_index* h) {
             (void)hipEventDestroy(ev.second);
         }
         void* dptrs[] = {h->X, h->xnorm, h->q_dev, h->qnorm, h->round_keys, h->acc_io, h->partial, h->out_s_dev, h->out_i_dev,
-                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr, h->wg_lossy};
+                         h->sample_heads, h->thr_keys, h->X16, h->sc_stats, h->sq, h->sctr, h->wg_lossy, h->dyn_ctrs};
         for (void* p : dptrs)
             if (p) (void)hipFree(p);
         void* hptrs[] = {h->q_pin, h->out_s_pin, h->out_i_pin, h->fb_pin};
@@ -827,12 +885,9 @@ extern "C" int rag_index_reserve(rag_index* h, int64_t n_total) {
 extern "C" int rag_index_add(rag_index* h, const float* rows_host, int64_t n) {
     if (!h || n < 0 || (n > 0 && !rows_host)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
-    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
-    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
-        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
-                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc0 = check_add_range(h, n)) return rc0;  // under the lock: set_id_offset validates and writes under it too
     int rc = grow_rows(h, h->n + n);
     if (rc) return rc;
     float* dst = h->X + (size_t)h->n * h->d8;
@@ -849,12 +904,9 @@ extern "C" int rag_index_add(rag_index* h, const float* rows_host, int64_t n) {
 extern "C" int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t n, void* stream) {
     if (!h || n < 0 || (n > 0 && !rows_dev)) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
-    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
-    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
-        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
-                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc0 = check_add_range(h, n)) return rc0;  // under the lock: set_id_offset validates and writes under it too
     int rc = grow_rows(h, h->n + n);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;  // NULL is HIP's default stream
@@ -872,12 +924,9 @@ extern "C" int rag_index_add_device(rag_index* h, const float* rows_dev, int64_t
 extern "C" int rag_index_add_synthetic(rag_index* h, int64_t n, uint64_t seed, int64_t row_number_offset) {
     if (!h || n < 0) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (n == 0) return RAG_OK;
-    if (h->n + n > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "more than 2^32-2 rows per index");
-    if (h->id_offset + h->n + n > 0xFFFFFFFFll)
-        return fail(RAG_ERR_UNSUPPORTED, "id_offset %lld + %lld rows exceeds 2^32-1: global ids must fit 32 bits",
-                    h->id_offset, (long long)(h->n + n));
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
+    if (int rc0 = check_add_range(h, n)) return rc0;  // under the lock: set_id_offset validates and writes under it too
     int rc = grow_rows(h, h->n + n);
     if (rc) return rc;
     const long long chunk = 1 << 20;  // rows per generator launch (bounds the inv scratch)
@@ -1008,6 +1057,92 @@ extern "C" int rag_index_search_device(rag_index* h, const float* queries_dev, i
     return search_device_locked(h, queries_dev, nq, k, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), st);
 }
 
+extern "C" int rag_index_search_device_ex(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                                          float* out_scores_dev, int64_t* out_ids_dev, int32_t mode,
+                                          uint32_t* flag_dev, void* stream) {
+    int rc = check_search_args(h, queries_dev, nq, k, out_scores_dev, out_ids_dev);
+    if (rc) return rc;
+    if (mode != RAG_SEARCH_DEFAULT && mode != RAG_SEARCH_EXACT_ONE_PASS && mode != RAG_SEARCH_DEFER_FALLBACK)
+        return fail(RAG_ERR_INVALID_ARG, "unknown search mode %d", mode);
+    if (mode == RAG_SEARCH_DEFER_FALLBACK && !flag_dev)
+        return fail(RAG_ERR_INVALID_ARG, "RAG_SEARCH_DEFER_FALLBACK needs a device word for the flag");
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    return search_device_locked(h, queries_dev, nq, k, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev),
+                                (hipStream_t)stream, nullptr, mode, flag_dev);
+}
+
+namespace {
+int ensure_host_out(rag_index* h, size_t on) {
+    int rc;
+    if (on > h->out_cap) {
+        if (h->out_s_dev) (void)hipFree(h->out_s_dev);
+        if (h->out_i_dev) (void)hipFree(h->out_i_dev);
+        h->out_s_dev = nullptr;
+        h->out_i_dev = nullptr;
+        h->out_cap = 0;
+        rc = dev_alloc(&h->out_s_dev, on);
+        if (rc) return rc;
+        rc = dev_alloc(&h->out_i_dev, on);
+        if (rc) return rc;
+        h->out_cap = on;
+    }
+    if (on > h->out_pin_cap) {
+        if (h->out_s_pin) (void)hipHostFree(h->out_s_pin);
+        if (h->out_i_pin) (void)hipHostFree(h->out_i_pin);
+        h->out_s_pin = nullptr;
+        h->out_i_pin = nullptr;
+        h->out_pin_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_s_pin), on * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_i_pin), on * sizeof(long long), hipHostMallocDefault));
+        h->out_pin_cap = on;
+    }
+    if (!h->fb_pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->fb_pin), sizeof(uint32_t), hipHostMallocDefault));
+    return RAG_OK;
+}
+
+// Results of the search just enqueued on `st` -> the caller's host buffers: one D2H per array, one sync; with a
+// deferred two-stage fallback (`deferred` = its epoch) the flag word rides along and the fp32 scan runs only
+// when a certificate failed.
+int finish_to_host(rag_index* h, const float* q_dev, int nq, int k, uint32_t deferred, float* out_scores, int64_t* out_ids,
+                   hipStream_t st) {
+    const size_t on = (size_t)nq * k;
+    HIP_TRY(hipMemcpyAsync(h->out_s_pin, h->out_s_dev, on * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h->out_i_pin, h->out_i_dev, on * sizeof(long long), hipMemcpyDeviceToHost, st));
+    if (deferred) HIP_TRY(hipMemcpyAsync(h->fb_pin, &h->sq->any_fallback, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (deferred && *h->fb_pin == deferred) {
+        // a certificate failed: the fp32 search of the block, restricted on the device to the flagged queries
+        int rc = search_exact_block(h, q_dev, nq, k, h->out_s_dev, h->out_i_dev, st, &h->sq->any_fallback,
+                                    h->sq->fallback, deferred);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(h->out_s_pin, h->out_s_dev, on * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h->out_i_pin, h->out_i_dev, on * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    std::memcpy(out_scores, h->out_s_pin, on * sizeof(float));
+    std::memcpy(out_ids, h->out_i_pin, on * sizeof(long long));
+    return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_index_search_device_host_out(rag_index* h, const float* queries_dev, int32_t nq, int32_t k,
+                                                float* out_scores, int64_t* out_ids, void* stream) {
+    int rc = check_search_args(h, queries_dev, nq, k, out_scores, out_ids);
+    if (rc) return rc;
+    if (nq == 0) return RAG_OK;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = (hipStream_t)stream;
+    rc = ensure_host_out(h, (size_t)nq * k);
+    if (rc) return rc;
+    uint32_t deferred = 0;
+    rc = search_device_locked(h, queries_dev, nq, k, h->out_s_dev, h->out_i_dev, st, &deferred);
+    if (rc) return rc;
+    return finish_to_host(h, queries_dev, nq, k, deferred, out_scores, out_ids, st);
+}
+
 extern "C" int rag_index_search(rag_index* h, const float* queries_host, int32_t nq, int32_t k, float* out_scores,
                                 int64_t* out_ids) {
     int rc = check_search_args(h, queries_host, nq, k, out_scores, out_ids);
@@ -1031,51 +1166,14 @@ extern "C" int rag_index_search(rag_index* h, const float* queries_host, int32_t
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->q_pin), qn * sizeof(float), hipHostMallocDefault));
         h->q_pin_cap = qn;
     }
-    if (on > h->out_cap) {
-        if (h->out_s_dev) (void)hipFree(h->out_s_dev);
-        if (h->out_i_dev) (void)hipFree(h->out_i_dev);
-        h->out_s_dev = nullptr;
-        h->out_i_dev = nullptr;
-        h->out_cap = 0;
-        rc = dev_alloc(&h->out_s_dev, on);
-        if (rc) return rc;
-        rc = dev_alloc(&h->out_i_dev, on);
-        if (rc) return rc;
-        h->out_cap = on;
-    }
-    if (on > h->out_pin_cap) {
-        if (h->out_s_pin) (void)hipHostFree(h->out_s_pin);
-        if (h->out_i_pin) (void)hipHostFree(h->out_i_pin);
-        h->out_s_pin = nullptr;
-        h->out_i_pin = nullptr;
-        h->out_pin_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_s_pin), on * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->out_i_pin), on * sizeof(long long), hipHostMallocDefault));
-        h->out_pin_cap = on;
-    }
+    rc = ensure_host_out(h, on);
+    if (rc) return rc;
     std::memcpy(h->q_pin, queries_host, qn * sizeof(float));
     HIP_TRY(hipMemcpyAsync(h->q_dev, h->q_pin, qn * sizeof(float), hipMemcpyHostToDevice, h->stream));
     uint32_t deferred = 0;
     rc = search_device_locked(h, h->q_dev, nq, k, h->out_s_dev, h->out_i_dev, h->stream, &deferred);
     if (rc) return rc;
-    if (deferred && !h->fb_pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->fb_pin), sizeof(uint32_t), hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(h->out_s_pin, h->out_s_dev, on * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->out_i_pin, h->out_i_dev, on * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-    if (deferred)
-        HIP_TRY(hipMemcpyAsync(h->fb_pin, &h->sq->any_fallback, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (deferred && *h->fb_pin == deferred) {
-        // a certificate failed: the fp32 search of the block, restricted on the device to the flagged queries
-        rc = search_exact_block(h, h->q_dev, nq, k, h->out_s_dev, h->out_i_dev, h->stream, &h->sq->any_fallback,
-                                h->sq->fallback, deferred);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(h->out_s_pin, h->out_s_dev, on * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->out_i_pin, h->out_i_dev, on * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    std::memcpy(out_scores, h->out_s_pin, on * sizeof(float));
-    std::memcpy(out_ids, h->out_i_pin, on * sizeof(long long));
-    return RAG_OK;
+    return finish_to_host(h, h->q_dev, nq, k, deferred, out_scores, out_ids, h->stream);
 }
 
 extern "C" int rag_index_get_rows(rag_index* h, int64_t row0, int64_t n, float* out_rows_host) {
@@ -1126,7 +1224,9 @@ extern "C" int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* s
 
 namespace {
 int merge_shards(int device, int metric, int n_shards, int nq, int k, const float* scores, long long score_stride,
-                 const long long* ids, long long id_stride, float* out_s, long long* out_i, void* stream) {
+                 const long long* ids, long long id_stride, float* out_s, long long* out_i, void* stream,
+                 const uint32_t* flags = nullptr, long long flag_stride = 0, uint32_t* any_flag = nullptr,
+                 float* host_s = nullptr, long long* host_i = nullptr, uint32_t* host_any = nullptr) {
     using namespace ragk;
     if (n_shards <= 0 || nq < 0 || k <= 0 || !scores || !ids || !out_s || !out_i)
         return fail(RAG_ERR_INVALID_ARG, "bad arguments");
@@ -1139,7 +1239,8 @@ int merge_shards(int device, int metric, int n_shards, int nq, int k, const floa
     if (nq == 0) return RAG_OK;
     DeviceGuard g(device);
     ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
-    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr, 0};
+    MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr, 0, flags, flag_stride, n_shards, any_flag,
+                host_s, host_i, host_any};
     const int look = merge_look(n_shards, k, k);
     launch_merge(src, n_shards, nq, k, look, mo, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1165,6 +1266,28 @@ extern "C" int rag_merge_topk_packed_device(int32_t device, int32_t metric, int3
     return merge_shards(device, metric, n_shards, nq, k, reinterpret_cast<const float*>(base + scores_offset_bytes),
                         shard_stride_bytes / 4, reinterpret_cast<const long long*>(base), shard_stride_bytes / 8,
                         out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), stream);
+}
+
+extern "C" int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
+                                                    const void* packed_dev, int64_t shard_stride_bytes,
+                                                    int64_t scores_offset_bytes, int64_t flag_offset_bytes,
+                                                    float* out_scores_dev, int64_t* out_ids_dev,
+                                                    uint32_t* any_flag_dev, void* host_mirror, void* stream) {
+    if (!packed_dev || shard_stride_bytes % 8 || scores_offset_bytes % 4 || shard_stride_bytes <= 0)
+        return fail(RAG_ERR_INVALID_ARG, "packed layout must keep ids 8-byte and scores 4-byte aligned");
+    if (!any_flag_dev || flag_offset_bytes < 0 || flag_offset_bytes % 4 || flag_offset_bytes + 4 > shard_stride_bytes)
+        return fail(RAG_ERR_INVALID_ARG, "flag word must be a 4-byte aligned word inside every shard's block");
+    if (nq <= 0) return fail(RAG_ERR_INVALID_ARG, "nq must be positive (the flags are reduced by query 0's workgroup)");
+    if (host_mirror && (reinterpret_cast<uintptr_t>(host_mirror) % 8))
+        return fail(RAG_ERR_INVALID_ARG, "host mirror must be 8-byte aligned");
+    const char* base = static_cast<const char*>(packed_dev);
+    char* hm = static_cast<char*>(host_mirror);
+    return merge_shards(device, metric, n_shards, nq, k, reinterpret_cast<const float*>(base + scores_offset_bytes),
+                        shard_stride_bytes / 4, reinterpret_cast<const long long*>(base), shard_stride_bytes / 8,
+                        out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), stream,
+                        reinterpret_cast<const uint32_t*>(base + flag_offset_bytes), shard_stride_bytes / 4, any_flag_dev,
+                        hm ? reinterpret_cast<float*>(hm + scores_offset_bytes) : nullptr, reinterpret_cast<long long*>(hm),
+                        hm ? reinterpret_cast<uint32_t*>(hm + flag_offset_bytes) : nullptr);
 }
 
 #ifdef RAGK_STAMPS

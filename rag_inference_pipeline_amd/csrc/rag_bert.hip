@@ -51,6 +51,16 @@ struct rag_bert {
     long long ids_cap = 0, types_cap = 0, cu_cap = 0;
     float* out_dev = nullptr;
     long long out_cap = 0;
+    // pinned staging of the asynchronous host-ids entry point: [ids | type_ids | cu_seqlens]
+    int* stage_pin = nullptr;
+    long long stage_cap = 0;
+    hipEvent_t stage_event = nullptr;   // the staging buffer's last upload
+    bool stage_used = false;
+    // the activation workspace is shared by every stream forwards are issued on: a forward that follows one
+    // on a different stream first waits for ws_event (same rule as the index's search workspace)
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
 };
 
 namespace {
@@ -229,6 +239,22 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     using namespace ragb;
     const rag_bert_config& c = h->cfg;
     const int H = c.hidden, I = c.intermediate, heads = c.n_heads, dh = H / heads;
+    if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    struct Mark {  // record the workspace hand-over point on every exit path
+        rag_bert* h;
+        hipStream_t st;
+        ~Mark() {
+            if (h->ws_event && hipEventRecord(h->ws_event, st) == hipSuccess) {
+                h->ws_stream = st;
+                h->ws_used = true;
+            }
+        }
+    } mark{h, st};
+    if (T > h->ws_tokens || nseq > h->ws_seqs) {
+        // the workspace is about to be reallocated: nothing enqueued earlier (on any stream) may still use it
+        if (h->ws_used) RAGC_HIP_TRY(hipEventSynchronize(h->ws_event));
+        RAGC_HIP_TRY(hipStreamSynchronize(st));
+    }
     int rc = ensure_ws(h, T, nseq);
     if (rc) return rc;
     const float* const* w = h->w.data();
@@ -250,8 +276,12 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     // Outputs that read first tokens only (CLS pooling, classifier head): after the last layer's attention nothing
     // but each sequence's first row is ever looked at, so that layer's output projection, LayerNorms and
     // feed-forward run on nseq rows instead of T — 9 of the 12 H^2 GEMM flops per token of a layer; one layer of
-    // six is 12 % of a MiniLM cross-encoder pass (32 x 100 pairs: 3200 rows instead of 178 000).  Exact: the
-    // rows that are computed go through the same kernels in the same order.
+    // six is 12 % of a MiniLM cross-encoder pass (32 x 100 pairs: 3200 rows instead of 178 000).  Same arithmetic
+    // per row, but not the same bits as a full pass: the GEMM kernel and its split-K count are picked from the row
+    // count (launch_gemm / launch_gemm_ln: split-bf16 above 1024 rows, fp32 MFMA at or below; split-K from the
+    // number of wave tiles), so with nseq rows instead of T the last layer's sums can be taken in another order.
+    // The two agree to fp32 rounding (tests/test_bert_gpu.py::test_first_token_last_layer_matches_the_full_pass
+    // holds them within 1e-5 on both sides of the 1024-row switch).
     const bool first_only_out = out_kind == RAG_BERT_OUT_CLS || out_kind == RAG_BERT_OUT_LOGITS || out_kind == RAG_BERT_OUT_PROBS;
     bool compact = false;  // h->pooled holds the final hidden state of the first tokens, one row per sequence
     for (int l = 0; l < c.n_layers; ++l) {
@@ -388,9 +418,13 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     h->cfg = c;
     h->device = device;
     h->w.assign(reinterpret_cast<const float* const*>(weights_dev), reinterpret_cast<const float* const*>(weights_dev) + n_weights);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->stage_event, hipEventDisableTiming) != hipSuccess) {
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->ws_event) (void)hipEventDestroy(h->ws_event);
         delete h;
-        return ragc_fail(RAG_ERR_HIP, "hipStreamCreate failed");
+        return ragc_fail(RAG_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
@@ -438,6 +472,9 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
             if (p) (void)hipFree(p);
         for (__bf16* p : h->wx)
             if (p) (void)hipFree(p);
+        if (h->stage_pin) (void)hipHostFree(h->stage_pin);
+        if (h->ws_event) (void)hipEventDestroy(h->ws_event);
+        if (h->stage_event) (void)hipEventDestroy(h->stage_event);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -458,24 +495,85 @@ extern "C" int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, cons
                           out_dev, (hipStream_t)stream);
 }
 
-extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* type_ids, const int32_t* cu_seqlens,
-                                int32_t nseq, int32_t out_kind, int32_t normalize, float* out) {
-    int rc = check_forward(h, nseq, out_kind);
-    if (rc) return rc;
-    if (!ids || !cu_seqlens || !out) return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer");
+namespace {
+// cu_seqlens checks shared by the host-ids entry points; returns the longest sequence through *max_len
+int check_host_batch(const rag_bert* h, const int32_t* cu_seqlens, int nseq, int* max_len) {
     if (cu_seqlens[0] != 0) return ragc_fail(RAG_ERR_INVALID_ARG, "cu_seqlens[0] must be 0");
-    int max_len = 0;
+    int mx = 0;
     for (int s = 0; s < nseq; ++s) {
         const int len = cu_seqlens[s + 1] - cu_seqlens[s];
         if (len <= 0) return ragc_fail(RAG_ERR_INVALID_ARG, "sequence %d is empty", s);
         if (len + h->cfg.pos_offset > h->cfg.max_positions)
             return ragc_fail(RAG_ERR_INVALID_ARG, "sequence %d has %d tokens; the model holds %d positions", s, len,
                              h->cfg.max_positions - h->cfg.pos_offset);
-        max_len = std::max(max_len, len);
+        mx = std::max(mx, len);
     }
+    *max_len = mx;
+    return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const int32_t* type_ids,
+                                          const int32_t* cu_seqlens, int32_t nseq, int32_t out_kind, int32_t normalize,
+                                          float* out_dev, void** stream_out) {
+    int rc = check_forward(h, nseq, out_kind);
+    if (rc) return rc;
+    if (!ids || !cu_seqlens || !out_dev || !stream_out) return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer");
+    int max_len = 0;
+    rc = check_host_batch(h, cu_seqlens, nseq, &max_len);
+    if (rc) return rc;
     const int T = cu_seqlens[nseq];
     RagcDeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = h->stream;
+    rc = grow(&h->ids_dev, &h->ids_cap, (long long)T);
+    if (rc) return rc;
+    if (type_ids && (rc = grow(&h->types_dev, &h->types_cap, (long long)T))) return rc;
+    rc = grow(&h->cu_dev, &h->cu_cap, (long long)nseq + 1);
+    if (rc) return rc;
+    // one pinned block [ids | type_ids | cu]: the caller's arrays are free again when this call returns, and the
+    // uploads are truly asynchronous (from pageable memory the runtime would stage them synchronously)
+    const long long need = 2LL * T + nseq + 1;
+    if (h->stage_used) RAGC_HIP_TRY(hipEventSynchronize(h->stage_event));  // the previous batch has left the block
+    if (need > h->stage_cap) {
+        if (h->stage_pin) (void)hipHostFree(h->stage_pin);
+        h->stage_pin = nullptr;
+        h->stage_cap = 0;
+        RAGC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->stage_pin), (size_t)(need + need / 2) * sizeof(int), hipHostMallocDefault));
+        h->stage_cap = need + need / 2;
+    }
+    int* pin_ids = h->stage_pin;
+    int* pin_types = h->stage_pin + T;
+    int* pin_cu = h->stage_pin + 2LL * T;
+    std::memcpy(pin_ids, ids, (size_t)T * sizeof(int));
+    if (type_ids) std::memcpy(pin_types, type_ids, (size_t)T * sizeof(int));
+    std::memcpy(pin_cu, cu_seqlens, (size_t)(nseq + 1) * sizeof(int));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->ids_dev, pin_ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    if (type_ids) RAGC_HIP_TRY(hipMemcpyAsync(h->types_dev, pin_types, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->cu_dev, pin_cu, (size_t)(nseq + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipEventRecord(h->stage_event, st));
+    h->stage_used = true;
+    rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind, normalize,
+                        out_dev, st);
+    if (rc) return rc;
+    *stream_out = (void*)st;
+    return RAG_OK;
+}
+
+extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* type_ids, const int32_t* cu_seqlens,
+                                int32_t nseq, int32_t out_kind, int32_t normalize, float* out) {
+    int rc = check_forward(h, nseq, out_kind);
+    if (rc) return rc;
+    if (!ids || !cu_seqlens || !out) return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer");
+    int max_len = 0;
+    rc = check_host_batch(h, cu_seqlens, nseq, &max_len);
+    if (rc) return rc;
+    const int T = cu_seqlens[nseq];
+    RagcDeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    // the id / cu buffers below are also the asynchronous entry point's: nothing of its may still be in flight
+    // when they are (re)allocated or overwritten from pageable memory
+    RAGC_HIP_TRY(hipStreamSynchronize(h->stream));
     rc = grow(&h->ids_dev, &h->ids_cap, (long long)T);
     if (rc) return rc;
     if (type_ids) {

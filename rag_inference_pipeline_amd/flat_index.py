@@ -12,7 +12,8 @@ import ctypes as C
 import numpy as np
 
 from . import _native
-from ._native import METRIC_INNER_PRODUCT, METRIC_L2  # noqa: F401  (re-exported)
+from ._native import (METRIC_INNER_PRODUCT, METRIC_L2,  # noqa: F401  (re-exported)
+                      SEARCH_DEFAULT, SEARCH_DEFER_FALLBACK, SEARCH_EXACT_ONE_PASS)
 
 SCREEN_OFF, SCREEN_FP16, SCREEN_INACTIVE = 0, 1, 2  # include/rag_amd.h RAG_SCREEN_*
 
@@ -100,6 +101,25 @@ class FlatIndex:
             self._handle(), C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(out_scores_ptr),
             C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
 
+    def search_device_ex(self, q_ptr: int, nq: int, k: int, out_scores_ptr: int, out_ids_ptr: int,
+                         mode: int = SEARCH_DEFAULT, flag_ptr: int = 0, stream: int = 0) -> None:
+        """search_device with the two-stage fallback policy chosen by the caller (rag_index_search_device_ex):
+        SEARCH_DEFER_FALLBACK leaves out the fallback launches and reports through the device word at
+        `flag_ptr` (1 = repeat the batch with SEARCH_EXACT_ONE_PASS)."""
+        _native.check(self._lib.rag_index_search_device_ex(
+            self._handle(), C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr),
+            int(mode), C.c_void_p(flag_ptr or None), C.c_void_p(stream)))
+
+    def search_from_device(self, q_ptr: int, nq: int, k: int, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
+        """(D, I) on the host for queries that are already in device memory (an embedder's device-resident
+        result on `stream`): rag_index_search_device_host_out — one read-back per array, one sync."""
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _native.check(self._lib.rag_index_search_device_host_out(
+            self._handle(), C.c_void_p(q_ptr), int(nq), int(k), _f32p(D), I.ctypes.data_as(C.POINTER(C.c_int64)),
+            C.c_void_p(stream)))
+        return D, I
+
     # -- two-stage exact search ------------------------------------------------------------
     def set_screening(self, mode: int | bool = SCREEN_FP16) -> None:
         """Keep a scaled fp16 copy of the corpus and answer k <= 100 searches by screening it, then
@@ -140,6 +160,19 @@ def merge_topk_device(device: int, metric: int, n_shards: int, nq: int, k: int, 
     _native.check(_native.lib().rag_merge_topk_device(
         int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(scores_ptr),
         C.c_void_p(ids_ptr), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
+
+
+def merge_topk_packed_flagged_device(device: int, metric: int, n_shards: int, nq: int, k: int, packed_ptr: int,
+                                     shard_stride_bytes: int, scores_offset_bytes: int, flag_offset_bytes: int,
+                                     out_scores_ptr: int, out_ids_ptr: int, any_flag_ptr: int, host_mirror_ptr: int = 0,
+                                     stream: int = 0) -> None:
+    """Merge out of the all-gather receive buffer and OR the shards' "not final" words into one device word
+    (rag_merge_topk_packed_flagged_device); with `host_mirror_ptr` (pinned host memory, one block's layout) the
+    kernel writes the result to the host as well."""
+    _native.check(_native.lib().rag_merge_topk_packed_flagged_device(
+        int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(packed_ptr), int(shard_stride_bytes),
+        int(scores_offset_bytes), int(flag_offset_bytes), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr),
+        C.c_void_p(any_flag_ptr), C.c_void_p(host_mirror_ptr or None), C.c_void_p(stream)))
 
 
 def merge_topk_packed_device(device: int, metric: int, n_shards: int, nq: int, k: int, packed_ptr: int,

@@ -114,6 +114,11 @@ class RetrievalExecutor:
         if not embedder:
             raise RuntimeError("Embedding generator not available")
         with stage_timers.track(STAGE_EMBEDDING):
+            # measurement mode (no embedding-keyed result cache): an embedder and an index that can hand the batch
+            # over in device memory do so — the embeddings are never needed on the host
+            if (getattr(self.settings, "disable_cache_for_profiling", True) and hasattr(embedder, "encode_device")
+                    and getattr(self.registry.get("faiss_store"), "accepts_device_embeddings", False)):
+                return embedder.encode_device([req.query for req in batch.requests])
             return embedder.encode([req.query for req in batch.requests])
 
     def clear_cache(self) -> None:

@@ -5,14 +5,27 @@ shards naturally — the top-k of a union is the top-k of the per-part top-k lis
 G-rank group owns the contiguous rows [N*r/G, N*(r+1)/G), reports GLOBAL ids (local row + base),
 and a search is:
 
-    local scan + top-k   ->   ONE all_gather of [ids | scores] (12 * nq * k bytes per rank)
+    local scan + top-k   ->   ONE all_gather of [ids | scores | flag] (12 * nq * k + 8 bytes per rank)
                          ->   merge of G sorted lists on every rank (one device kernel that
-                              reads the gather's receive buffer in place)
+                              reads the gather's receive buffer in place and ORs the flags)
 
-Over xGMI the gather is latency-bound (3.84 KB per rank at nq=32, k=10), so the packed buffer goes
+Over xGMI the gather is latency-bound (3.85 KB per rank at nq=32, k=10), so the packed buffer goes
 out as a single collective rather than one per tensor.  `torch.distributed` supplies the group
 (backend "nccl" = RCCL on ROCm); with the "gloo" backend the packed buffer is staged through host
 memory, which is how the multi-rank path is exercised on CPU-only and single-GPU machines.
+
+The flag.  With the two-stage search (rag_index_set_screening) a rank's local list is exact unless one
+of its per-query certificates failed.  Instead of enqueueing the fp32 fallback behind every search
+(two self-disabling launches and two kernel boundaries per batch), a rank runs its local search with
+RAG_SEARCH_DEFER_FALLBACK: its "not final" word travels in its block of the all-gather, the merge
+kernel ORs the G words into one, and only when that word is set — on every rank alike, since every
+rank merges the same gathered buffer — do the ranks repeat the batch through the one-pass fp32 scan
+and gather again.  The caller reads one word back with the results it was going to read anyway.
+
+Serving (the product path: FAISSStore.search on rank 0 -> leader_search).  A request is ONE
+fixed-size message `[4 x int64 head | max_batch x d fp32]` that rank 0 fills in pinned memory,
+uploads once and broadcasts once; followers read back only the 32-byte head and hand the query
+*device pointer* inside the message buffer straight to the local search.
 """
 
 from __future__ import annotations
@@ -22,8 +35,10 @@ from typing import Any, Callable, Protocol
 
 import numpy as np
 
+from ._native import SEARCH_DEFER_FALLBACK, SEARCH_EXACT_ONE_PASS
 
 OP_SHUTDOWN, OP_SEARCH, OP_RERANK = 0, 1, 2  # first word of the leader's request head
+HEAD_BYTES = 32                               # [op, nq, k, d] as int64
 
 
 def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
@@ -31,12 +46,12 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return n_total * rank // world, n_total * (rank + 1) // world
 
 
-def pack_layout(nq: int, k: int) -> tuple[int, int]:
-    """(byte offset of the score block, bytes per rank) of one rank's packed result buffer:
-    nq*k int64 ids, then nq*k fp32 scores, padded to a multiple of 8 bytes so that every rank's id
-    block stays 8-byte aligned in the gathered buffer."""
+def pack_layout(nq: int, k: int) -> tuple[int, int, int]:
+    """(byte offset of the score block, byte offset of the flag word, bytes per rank) of one rank's
+    packed result buffer: nq*k int64 ids, nq*k fp32 scores, one uint32 "not final" word, padded to a
+    multiple of 8 bytes so that every rank's id block stays 8-byte aligned in the gathered buffer."""
     n = nq * k
-    return 8 * n, (12 * n + 7) // 8 * 8
+    return 8 * n, 12 * n, (12 * n + 4 + 7) // 8 * 8
 
 
 class _LocalIndex(Protocol):
@@ -44,16 +59,51 @@ class _LocalIndex(Protocol):
                       stream: int = 0) -> None: ...
 
 
+class _Slot:
+    """One set of per-(nq, k) buffers: a search in flight owns it from submit() to collect()."""
+
+    def __init__(self, owner: "ShardedFlatIndex", nq: int, k: int) -> None:
+        torch = owner._torch
+        dev, world = owner.device, owner.world
+        self.nq, self.k = nq, k
+        s_off, f_off, nbytes = pack_layout(nq, k)
+        self.s_off, self.f_off, self.nbytes = s_off, f_off, nbytes
+
+        def views(buf: Any) -> tuple[Any, Any, Any]:
+            return (buf[:s_off].view(torch.int64).view(nq, k), buf[s_off:f_off].view(torch.float32).view(nq, k),
+                    buf[f_off:f_off + 4].view(torch.int32))
+
+        self.pack = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.pack_i, self.pack_s, self.pack_f = views(self.pack)
+        self.gathered = torch.empty(world * nbytes, dtype=torch.uint8, device=dev)
+        # merged result in the same layout: ids | scores | OR of the ranks' flags — ONE read-back per batch
+        self.res = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.out_i, self.out_s, self.out_any = views(self.res)
+        on_gpu = dev.type == "cuda"
+        self.res_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if on_gpu else self.res
+        self.host_i, self.host_s, self.host_any = views(self.res_host)
+        self.event = torch.cuda.Event() if on_gpu else None
+        if owner.backend != "nccl":
+            self.pack_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if on_gpu \
+                else torch.empty(nbytes, dtype=torch.uint8)
+            self.gathered_host = torch.empty(world * nbytes, dtype=torch.uint8)
+        self.pending: Any = None   # the query tensor of the search in flight (kept alive for a repeat)
+        self.repeats = 0           # fp32 repeats this slot has run (tests, stats)
+
+
 class ShardedFlatIndex:
     """Collective wrapper around one local index per rank.
 
     `local` is this rank's FlatIndex (already holding its shard, id offset set to the shard base).
     `merge` merges (world, nq, k) score/id tensors into (nq, k) outputs; the default is the device
-    kernel behind rag_merge_topk_device.
+    kernel behind rag_merge_topk_packed_flagged_device.  `dim` is the index dimension (default
+    `local.d`) and `max_batch` the largest batch one serving message carries (the reference's
+    retrieval_batch_size, config/__init__.py:278; larger batches go out as several requests).
     """
 
     def __init__(self, local: _LocalIndex, metric: int = 0, device: int | str | None = None, group: Any = None,
-                 merge: Callable[..., None] | None = None) -> None:
+                 merge: Callable[..., None] | None = None, dim: int | None = None, max_batch: int = 32,
+                 depth: int = 2) -> None:
         import torch
         import torch.distributed as dist
 
@@ -72,93 +122,180 @@ class ShardedFlatIndex:
         else:
             self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         self._merge = merge
-        self._bufs: dict[tuple[int, int], dict[str, Any]] = {}
+        self.dim = int(dim if dim is not None else getattr(local, "d"))
+        self.max_batch = int(max_batch)
+        self.depth = max(1, int(depth))
+        self._slots: dict[tuple[int, int], list[_Slot]] = {}
+        self._next: dict[tuple[int, int], int] = {}
+        self.repeats = 0  # batches repeated through the fp32 scan because some rank's certificate failed
         # One request at a time on the serving channel.  The reference's scheduler starts every flushed
         # batch as its own task on a pool thread (gateway/batch_scheduler.py:286-288), so rank 0 can be
         # inside search()/rerank_batch() on several threads at once; a request is a SEQUENCE of
-        # collectives (head, payload, gather, merge, read-back of the per-shape buffers) that the
-        # followers replay in order, so two of them must never interleave.  Re-entrant: leader_search
-        # holds it around search().
+        # collectives (message, gather, merge, possibly a repeat, read-back of the per-shape buffers) that
+        # the followers replay in order, so two of them must never interleave.  Re-entrant: leader_search
+        # holds it around the search.
         self._lock = threading.RLock()
+        # the serving message: [4 x int64 head | max_batch x dim fp32], filled by rank 0, ONE broadcast per request
+        self._msg_bytes = HEAD_BYTES + 4 * self.max_batch * self.dim
+        on_gpu = self.device.type == "cuda"
+        self._msg_host = torch.zeros(self._msg_bytes, dtype=torch.uint8)
+        self._msg_event = None
+        if on_gpu:
+            self._msg_host = self._msg_host.pin_memory()
+            self._msg_dev = torch.zeros(self._msg_bytes, dtype=torch.uint8, device=self.device)
+            self._msg_event = torch.cuda.Event()
+        else:
+            self._msg_dev = self._msg_host
+        self._msg_head_np = self._msg_host[:HEAD_BYTES].numpy().view(np.int64)
+        self._msg_q_np = self._msg_host[HEAD_BYTES:].numpy().view(np.float32)
+        self._msg_q_dev = self._msg_dev[HEAD_BYTES:].view(torch.float32)
+        # followers over RCCL: the message arrives in device memory and only its head comes back to the host
+        self._head_pin = torch.zeros(HEAD_BYTES, dtype=torch.uint8).pin_memory() \
+            if on_gpu and self.backend == "nccl" else None
 
     # -- buffers ---------------------------------------------------------------------------------
-    def _buffers(self, nq: int, k: int) -> dict[str, Any]:
+    def _slot(self, nq: int, k: int) -> _Slot:
         key = (nq, k)
-        b = self._bufs.get(key)
-        if b is None:
-            torch = self._torch
-            s_off, nbytes = pack_layout(nq, k)
-            pack = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-            b = {
-                "pack": pack,
-                "pack_i": pack[:s_off].view(torch.int64).view(nq, k),
-                "pack_s": pack[s_off:s_off + 4 * nq * k].view(torch.float32).view(nq, k),
-                "gathered": torch.empty(self.world * nbytes, dtype=torch.uint8, device=self.device),
-                "out_s": torch.empty((nq, k), dtype=torch.float32, device=self.device),
-                "out_i": torch.empty((nq, k), dtype=torch.int64, device=self.device),
-            }
-            if self.backend != "nccl":
-                b["pack_host"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory() \
-                    if self.device.type == "cuda" else torch.empty(nbytes, dtype=torch.uint8)
-                b["gathered_host"] = torch.empty(self.world * nbytes, dtype=torch.uint8)
-            self._bufs[key] = b
-        return b
+        ring = self._slots.get(key)
+        if ring is None:
+            ring = self._slots[key] = [_Slot(self, nq, k) for _ in range(self.depth)]
+            self._next[key] = 0
+        i = self._next[key]
+        self._next[key] = (i + 1) % len(ring)
+        slot = ring[i]
+        if slot.pending is not None:
+            raise RuntimeError(f"more than {self.depth} searches of shape ({nq}, {k}) in flight: collect() the oldest "
+                               "before the next submit()")
+        return slot
+
+    def _stream(self) -> int:
+        return self._torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
 
     # -- the collective step -----------------------------------------------------------------------
-    def _all_gather(self, b: dict[str, Any]) -> None:
+    def _all_gather(self, s: _Slot) -> None:
         dist = self._dist
         if self.backend == "nccl":
-            dist.all_gather_into_tensor(b["gathered"], b["pack"], group=self.group)
+            dist.all_gather_into_tensor(s.gathered, s.pack, group=self.group)
             return
         # host-staged gather (gloo): same bytes, same layout
-        b["pack_host"].copy_(b["pack"])
-        dist.all_gather_into_tensor(b["gathered_host"], b["pack_host"], group=self.group)
-        b["gathered"].copy_(b["gathered_host"])
+        s.pack_host.copy_(s.pack)
+        dist.all_gather_into_tensor(s.gathered_host, s.pack_host, group=self.group)
+        s.gathered.copy_(s.gathered_host)
+
+    def _local_search(self, s: _Slot, queries: Any, mode: int) -> None:
+        ex = getattr(self.local, "search_device_ex", None)
+        if ex is not None:
+            ex(queries.data_ptr(), s.nq, s.k, s.pack_s.data_ptr(), s.pack_i.data_ptr(), mode, s.pack_f.data_ptr(),
+               self._stream())  # the flag word is written in every mode (0: final)
+        else:  # a local index without the two-stage choice (test doubles): its result is final
+            self.local.search_device(queries.data_ptr(), s.nq, s.k, s.pack_s.data_ptr(), s.pack_i.data_ptr(),
+                                     self._stream())
+            s.pack_f.zero_()
+
+    def _gather_and_merge(self, s: _Slot) -> None:
+        torch = self._torch
+        self._all_gather(s)
+        if self._merge is not None:  # test double: unpack on the host side of the tensor API
+            g = s.gathered.view(self.world, s.nbytes)
+            all_i = g[:, :s.s_off].contiguous().view(torch.int64).view(self.world, s.nq, s.k)
+            all_s = g[:, s.s_off:s.f_off].contiguous().view(torch.float32).view(self.world, s.nq, s.k)
+            self._merge(self.metric, all_s, all_i, s.out_s, s.out_i)
+            s.out_any.copy_(g[:, s.f_off:s.f_off + 4].contiguous().view(torch.int32).view(self.world).max().reshape(1))
+        else:
+            from .flat_index import merge_topk_packed_flagged_device
+
+            # the merge kernel writes ids, scores and the OR-ed flag to the pinned host block as well: no read-back copy
+            merge_topk_packed_flagged_device(self.device.index or 0, self.metric, self.world, s.nq, s.k,
+                                             s.gathered.data_ptr(), s.nbytes, s.s_off, s.f_off, s.out_s.data_ptr(),
+                                             s.out_i.data_ptr(), s.out_any.data_ptr(),
+                                             s.res_host.data_ptr() if s.event is not None else 0, self._stream())
+            if s.event is not None:
+                s.event.record()
+            return
+        if s.event is not None:  # test-double merge on a GPU: ids, scores and the flag come back in one copy
+            s.res_host.copy_(s.res, non_blocking=True)
+            s.event.record()
+
+    def submit(self, queries: Any, k: int) -> _Slot:
+        """Collective, asynchronous: every rank passes the same (nq, d) float32 device tensor (kept alive and
+        unchanged until collect()).  Enqueues local search -> all-gather -> merge -> read-back on the current
+        stream and returns at once; up to `depth` searches of one shape may be in flight."""
+        nq = int(queries.shape[0])
+        s = self._slot(nq, int(k))
+        s.pending = queries
+        self._local_search(s, queries, SEARCH_DEFER_FALLBACK)
+        self._gather_and_merge(s)
+        return s
+
+    def collect(self, s: _Slot) -> tuple[Any, Any]:
+        """Collective: wait for submit()'s search; if some rank's two-stage certificate failed (the same word
+        on every rank) repeat the batch through the one-pass fp32 scan and gather again.  Returns the merged
+        (scores, ids) device tensors — views into the slot, valid until it is reused; `slot.host_s` /
+        `slot.host_i` hold the same values in pinned host memory."""
+        if s.pending is None:
+            raise RuntimeError("collect() without a submit() in flight on this slot")
+        if s.event is not None:
+            s.event.synchronize()
+        if int(s.host_any[0]) != 0:
+            self._local_search(s, s.pending, SEARCH_EXACT_ONE_PASS)
+            self._gather_and_merge(s)
+            if s.event is not None:
+                s.event.synchronize()
+            s.repeats += 1
+            self.repeats += 1
+        s.pending = None
+        return s.out_s, s.out_i
 
     def search_tensors(self, queries: Any, k: int) -> tuple[Any, Any]:
         """Collective: every rank passes the same (nq, d) float32 device tensor; every rank gets the
-        merged (scores, ids) device tensors (views into per-shape buffers, valid until the next call)."""
-        torch = self._torch
-        nq = int(queries.shape[0])
-        b = self._buffers(nq, k)
-        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        self.local.search_device(queries.data_ptr(), nq, k, b["pack_s"].data_ptr(), b["pack_i"].data_ptr(), stream)
-        self._all_gather(b)
-        s_off, nbytes = pack_layout(nq, k)
-        if self._merge is not None:  # test double: unpack on the host side of the tensor API
-            g = b["gathered"].view(self.world, nbytes)
-            all_i = g[:, :s_off].contiguous().view(torch.int64).view(self.world, nq, k)
-            all_s = g[:, s_off:s_off + 4 * nq * k].contiguous().view(torch.float32).view(self.world, nq, k)
-            self._merge(self.metric, all_s, all_i, b["out_s"], b["out_i"])
-        else:
-            from .flat_index import merge_topk_packed_device
-
-            merge_topk_packed_device(self.device.index or 0, self.metric, self.world, nq, k, b["gathered"].data_ptr(),
-                                     nbytes, s_off, b["out_s"].data_ptr(), b["out_i"].data_ptr(), stream)
-        return b["out_s"], b["out_i"]
+        merged (scores, ids) device tensors (views into per-shape buffers, valid until `depth` further
+        searches of this shape).  Waits for the result (the flag decides whether it is final); callers that
+        want several batches in flight use submit() / collect()."""
+        return self.collect(self.submit(queries, k))
 
     def search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
         """Host convenience (collective): numpy in, numpy out, same contract as FlatIndex.search."""
         torch = self._torch
         with self._lock:  # the per-shape buffers are shared: keep them until the result is on the host
             q = torch.from_numpy(np.ascontiguousarray(queries, dtype=np.float32)).to(self.device)
-            s, i = self.search_tensors(q, k)
-            if self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)
-            return s.cpu().numpy().copy(), i.cpu().numpy().copy()
+            s = self.submit(q, k)
+            self.collect(s)
+            return s.host_s.numpy().copy(), s.host_i.numpy().copy()
 
     # -- serving: rank 0 answers requests, the other ranks follow -------------------------------------
     # The reference's retrieval node is ONE process (uvicorn) calling index.search(); with the corpus
-    # split over G ranks, rank 0 keeps that role.  Every request it serves starts with a 4-word head
-    # [op, nq, k, d] broadcast to the followers, which sit in follower_loop(): OP_SEARCH ships the batch
-    # and runs the collective search; other ops run a handler a component registered (the reranker's
-    # query-sharded pass, components/reranker.py); OP_SHUTDOWN ends the loop.
-    def _ctl_device(self) -> Any:
-        return self.device if self.backend == "nccl" else self._torch.device("cpu")
+    # split over G ranks, rank 0 keeps that role.  Every request it serves is one fixed-size message
+    # [op, nq, k, d | queries] broadcast to the followers, which sit in follower_loop(): OP_SEARCH runs
+    # the collective search on the queries inside the message; other ops run a handler a component
+    # registered (the reranker's query-sharded pass, components/reranker.py); OP_SHUTDOWN ends the loop.
+    def _broadcast_msg(self) -> None:
+        """Rank 0 has filled the pinned message; afterwards every rank holds it in `_msg_dev`."""
+        dist = self._dist
+        if self.backend == "nccl":
+            if self.rank == 0:
+                self._msg_dev.copy_(self._msg_host, non_blocking=True)  # the batch is uploaded once
+                self._msg_event.record()
+            dist.broadcast(self._msg_dev, src=0, group=self.group)
+        else:
+            dist.broadcast(self._msg_host, src=0, group=self.group)
+            if self._msg_dev is not self._msg_host:
+                self._msg_dev.copy_(self._msg_host)
+
+    def _msg_free(self) -> None:
+        """Rank 0: the previous request's upload must have left the pinned message before it is refilled."""
+        if self._msg_event is not None and self.backend == "nccl":
+            self._msg_event.synchronize()
 
     def _send_head(self, op: int, nq: int = 0, k: int = 0, d: int = 0) -> None:
-        head = self._torch.tensor([op, nq, k, d], dtype=self._torch.int64, device=self._ctl_device())
-        self._dist.broadcast(head, src=0, group=self.group)
+        self._msg_free()
+        self._msg_head_np[:] = (op, nq, k, d)
+        self._broadcast_msg()
+
+    def _fill_msg(self, q: np.ndarray) -> None:
+        """Rank 0: the batch into the pinned message (converting to fp32 if needed)."""
+        self._msg_free()
+        nq = q.shape[0]
+        self._msg_q_np[:nq * self.dim].reshape(nq, self.dim)[...] = q
 
     def register_handler(self, op: int, fn: Callable[[], None]) -> None:
         """Followers: run `fn()` when the leader announces `op` (fn performs the matching collectives)."""
@@ -167,7 +304,7 @@ class ShardedFlatIndex:
         self._handlers[int(op)] = fn
 
     def exclusive(self) -> Any:
-        """`with link.exclusive():` — hold the serving channel for one whole request: the head, every
+        """`with link.exclusive():` — hold the serving channel for one whole request: the message, every
         collective that follows it and the read-back of the result.  leader_search() takes it itself;
         a component that drives its own exchange through leader_call() (the reranker) wraps the
         exchange in it."""
@@ -182,33 +319,47 @@ class ShardedFlatIndex:
             self._send_head(int(op))
 
     def leader_search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
-        """Rank 0: broadcast the batch, run the collective search, return the merged result."""
+        """Rank 0: ship the batch in one broadcast, run the collective search, return the merged result."""
         if self.rank != 0:
             raise RuntimeError("leader_search() is for rank 0; other ranks run follower_loop()")
-        torch, dist = self._torch, self._dist
-        q = np.ascontiguousarray(queries, dtype=np.float32)
+        q = np.asarray(queries)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"queries must have shape (nq, {self.dim}), got {q.shape}")
+        nq_total, k = int(q.shape[0]), int(k)
+        D = np.empty((nq_total, k), dtype=np.float32)
+        I = np.empty((nq_total, k), dtype=np.int64)
         with self._lock:
-            self._send_head(OP_SEARCH, q.shape[0], int(k), q.shape[1])
-            qt = torch.from_numpy(q).to(self._ctl_device())
-            dist.broadcast(qt, src=0, group=self.group)
-            return self.search(q, k)
+            for lo in range(0, nq_total, self.max_batch):
+                nq = min(self.max_batch, nq_total - lo)
+                self._fill_msg(q[lo:lo + nq])
+                self._send_head(OP_SEARCH, nq, k, self.dim)
+                s = self.submit(self._msg_q_dev[:nq * self.dim].view(nq, self.dim), k)
+                self.collect(s)
+                D[lo:lo + nq] = s.host_s.numpy()
+                I[lo:lo + nq] = s.host_i.numpy()
+        return D, I
 
     def follower_loop(self) -> int:
         """Ranks > 0: serve the leader's requests until it sends shutdown(); returns the number served."""
         if self.rank == 0:
             raise RuntimeError("follower_loop() is for ranks other than 0")
-        torch, dist = self._torch, self._dist
+        torch = self._torch
         served = 0
+        head_np = self._head_pin.numpy().view(np.int64) if self._head_pin is not None else self._msg_head_np
         while True:
-            head = torch.zeros(4, dtype=torch.int64, device=self._ctl_device())
-            dist.broadcast(head, src=0, group=self.group)
-            op, nq, k, d = (int(v) for v in head.tolist())
+            self._broadcast_msg()
+            if self._head_pin is not None:  # only the 32-byte head comes back to the host
+                self._head_pin.copy_(self._msg_dev[:HEAD_BYTES], non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+            op, nq, k, d = (int(v) for v in head_np)
             if op == OP_SHUTDOWN:
                 return served
             if op == OP_SEARCH:
-                qt = torch.empty((nq, d), dtype=torch.float32, device=self._ctl_device())
-                dist.broadcast(qt, src=0, group=self.group)
-                self.search(qt.cpu().numpy(), k)
+                if d != self.dim or not 0 < nq <= self.max_batch:
+                    raise RuntimeError(f"follower received a search of {nq} x {d}; this rank serves up to "
+                                       f"{self.max_batch} x {self.dim}")
+                with self._lock:
+                    self.collect(self.submit(self._msg_q_dev[:nq * d].view(nq, d), k))
             elif op in self._handlers:
                 self._handlers[op]()
             else:

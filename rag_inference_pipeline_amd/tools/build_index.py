@@ -14,9 +14,11 @@ One process per GPU: started under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in t
 and writes its rows at their byte offset of the one output file; rank 0 writes the sidecar once every
 rank has left its `.done` marker.  No collective is involved.
 
-The ranks of one build share a BUILD ID (--build-id, else the launcher's TORCHELASTIC_RUN_ID): a marker
-is `{"build_id", "rank", "rows"}`, rank 0 accepts only markers of its own build whose row counts add up to
-the table, and no rank ever deletes another rank's marker — so neither a rank that finished before rank 0
+The ranks of one build share a BUILD ID (--build-id, else the launcher's TORCHELASTIC_RUN_ID when it is a real
+id: torchrun's static rendezvous exports the literal "none" for every run, which is treated as absent): a
+marker is `{"build_id", "rank", "rows", "n", "model", "field"}`, rank 0 accepts only markers of its own build
+and job (same table size, model and field) whose row counts add up to the table, and no rank ever deletes
+another rank's marker — so neither a rank that finished before rank 0
 started nor the leftovers of a crashed earlier build can be mistaken for each other.  The sidecar of an
 earlier build is removed first and the new one appears atomically, last.
 """
@@ -56,10 +58,13 @@ def build_index(documents_dir: str, model: str, out: str, metric: str = "ip", fi
         raise ValueError("field must be 'content' or 'title'")
     if not 0 <= rank < world:
         raise ValueError(f"rank {rank} outside world {world}")
-    build_id = build_id or os.environ.get("TORCHELASTIC_RUN_ID") or ("single" if world == 1 else None)
+    run_id = (os.environ.get("TORCHELASTIC_RUN_ID") or "").strip()
+    if run_id.lower() == "none":  # torchrun's default --rdzv-id under the static rendezvous: the same for every run
+        run_id = ""
+    build_id = build_id or run_id or ("single" if world == 1 else None)
     if not build_id:
-        raise ValueError("a multi-rank build needs one build id shared by its ranks: pass --build-id (torchrun "
-                         "exports TORCHELASTIC_RUN_ID, which is used when present)")
+        raise ValueError("a multi-rank build needs one build id shared by its ranks: pass --build-id (torchrun's "
+                         "TORCHELASTIC_RUN_ID is used only when it is a real id, not the default \"none\")")
     marker = lambda r: Path(f"{out}.part{r}.done")  # noqa: E731
     marker(rank).unlink(missing_ok=True)            # only ever this rank's own marker
     if rank == 0:
@@ -100,13 +105,15 @@ def build_index(documents_dir: str, model: str, out: str, metric: str = "ip", fi
     con.close()
     embedder.unload()
     tmp = Path(f"{out}.part{rank}.done.tmp")
-    tmp.write_text(json.dumps({"build_id": build_id, "rank": rank, "rows": done - row_lo}))
+    job = {"n": int(n), "model": model, "field": field}
+    tmp.write_text(json.dumps({"build_id": build_id, "rank": rank, "rows": done - row_lo, **job}))
     os.replace(tmp, marker(rank))                   # a marker is either absent or complete
     if rank == 0:
         deadline = time.time() + wait_seconds
         while True:
             marks = [_read_marker(marker(r)) for r in range(world)]
-            mine = [m if m and m.get("build_id") == build_id and m.get("rank") == r else None for r, m in enumerate(marks)]
+            mine = [m if m and m.get("build_id") == build_id and m.get("rank") == r
+                    and all(m.get(key) == val for key, val in job.items()) else None for r, m in enumerate(marks)]
             if all(mine):
                 break
             if time.time() > deadline:
@@ -138,7 +145,8 @@ def main() -> None:
     ap.add_argument("--rank", type=int, default=int(os.environ.get("RANK", "0")))
     ap.add_argument("--world", type=int, default=int(os.environ.get("WORLD_SIZE", "1")))
     ap.add_argument("--build-id", default=None, help="one string shared by the ranks of this build "
-                                                     "(default: TORCHELASTIC_RUN_ID; required when --world > 1 without it)")
+                                                     "(default: TORCHELASTIC_RUN_ID unless it is torchrun's default \"none\"; "
+                                                     "required when --world > 1 without one)")
     a = ap.parse_args()
     device = a.device if a.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
     n, d = build_index(a.documents_dir, a.model, a.out, a.metric, a.field, a.batch_docs, device, a.rank, a.world,

@@ -1,12 +1,19 @@
 """One shard's step of the 8-GPU series, on one GPU: 1.25M x 768 rows, batch 32, k = 10.
 
-Two figures per search mode, timed like bench.py (device-resident queries, back-to-back steps):
-  local    rag_index_search_device alone: scan -> merge (one-pass) or prep -> screen -> resolve -> fallback
-           (two-stage).  This is the step "before the collective".
-  sharded  the same through ShardedFlatIndex over a real nccl process group of world size 1
-           (... -> all_gather_into_tensor -> merge of the gathered lists): what every rank of the N-GPU
-           run executes; the N-GPU step is this plus the collective's latency over xGMI.
-Prints one JSON object (committed as profiles/r02_shard_step.json)."""
+Per search mode (one-pass fp32 scan / exact two-stage search), through a real `nccl` process group of world
+size 1 (every collective call the N-GPU run makes is made; what is missing is the other ranks' latency):
+
+  search_device     rag_index_search_device alone, queries resident in HBM, back-to-back: scan -> merge
+                    (one-pass) or screen -> resolve -> two self-disabling fallback launches (two-stage)
+  search_deferred   rag_index_search_device_ex(RAG_SEARCH_DEFER_FALLBACK): the two-stage search without the
+                    fallback launches (its flag word is what the sharded step ships)
+  search_tensors    ShardedFlatIndex: local search (deferred) -> all_gather_into_tensor -> merge + flag OR ->
+                    one read-back; the host waits for the flag after every batch
+  pipelined         the same through submit() / collect() with two batches in flight (what bench.py times at N > 1)
+  leader_search     the step the PRODUCT serves (FAISSStore.search on rank 0): host queries -> pinned message ->
+                    one upload -> one broadcast -> search_tensors -> ids and scores on the host
+
+Prints one JSON object (committed as profiles/r03_shard_step.json)."""
 import json
 import os
 import sys
@@ -18,7 +25,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from oracle import flat as oracle
-from rag_inference_pipeline_amd.flat_index import FlatIndex, SCREEN_FP16
+from rag_inference_pipeline_amd.flat_index import FlatIndex, SCREEN_FP16, SEARCH_DEFER_FALLBACK
 from rag_inference_pipeline_amd.sharded import ShardedFlatIndex
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
@@ -26,27 +33,54 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 d, B, k = 768, 32, 10
 idx = FlatIndex(d); idx.add_synthetic(rows, 1234)
 sh = ShardedFlatIndex(idx, 0, device=0)
-Q = torch.from_numpy(oracle.synth_rows(4321, 0, B, d)).cuda()
+Qh = oracle.synth_rows(4321, 0, B, d)
+Q = torch.from_numpy(Qh).cuda()
 out_s = torch.empty((B, k), dtype=torch.float32, device="cuda")
 out_i = torch.empty((B, k), dtype=torch.int64, device="cuda")
+flag = torch.zeros(1, dtype=torch.int32, device="cuda")
 sptr = torch.cuda.current_stream().cuda_stream
 
 
-def timed(fn):
+def timed(fn, drain=None):
     for _ in range(10):
         fn()
+    if drain:
+        drain()
     torch.cuda.synchronize()
     idx.profile_enable(True); idx.profile(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    if drain:
+        drain()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
     ms, n = idx.profile(reset=True); idx.profile_enable(False)
-    return el * 1e3, ms / n
+    return el * 1e3, ms / max(n, 1)
 
 
-res = {"rows": rows, "dim": d, "batch": B, "k": k, "steps": steps}
+def percentiles(fn, n=100):
+    per = []
+    for _ in range(n):
+        t1 = time.perf_counter(); fn(); per.append(time.perf_counter() - t1)
+    return float(np.median(per) * 1e3), float(np.percentile(per, 95) * 1e3)
+
+
+pend = []
+
+
+def pipelined():
+    pend.append(sh.submit(Q, k))
+    if len(pend) > 1:
+        sh.collect(pend.pop(0))
+
+
+def drain():
+    while pend:
+        sh.collect(pend.pop(0))
+
+
+res = {"rows": rows, "dim": d, "batch": B, "k": k, "steps": steps, "world": 1, "backend": sh.backend}
 ref = None
 for mode in ("one_pass", "two_stage"):
     if mode == "two_stage":
@@ -54,17 +88,29 @@ for mode in ("one_pass", "two_stage"):
     local_ms, scan_ms = timed(lambda: idx.search_device(Q.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr))
     torch.cuda.synchronize()
     ids = out_i.cpu().numpy().copy(); sc = out_s.cpu().numpy().copy()
-    sharded_ms, _ = timed(lambda: sh.search_tensors(Q, k))
+    deferred_ms, _ = timed(lambda: idx.search_device_ex(Q.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(),
+                                                        SEARCH_DEFER_FALLBACK, flag.data_ptr(), sptr))
+    sync_ms, _ = timed(lambda: sh.search_tensors(Q, k))
+    pipe_ms, _ = timed(pipelined, drain)
     s2, i2 = sh.search_tensors(Q, k); torch.cuda.synchronize()
     same = bool(np.array_equal(i2.cpu().numpy(), ids) and np.array_equal(s2.cpu().numpy().view(np.uint32), sc.view(np.uint32)))
+    lead_ms, _ = timed(lambda: sh.leader_search(Qh, k))
+    lead_p50, lead_p95 = percentiles(lambda: sh.leader_search(Qh, k))
+    Dl, Il = sh.leader_search(Qh, k)
+    lead_same = bool(np.array_equal(Il, ids) and np.array_equal(Dl.view(np.uint32), sc.view(np.uint32)))
+    host_ms, _ = timed(lambda: idx.search(Qh, k))   # one GPU, no group: what FAISSStore.search costs without sharding
     if ref is None:
         ref = (ids, sc)
-    res[mode] = {"local_step_ms": round(local_ms, 4), "scan_kernel_ms": round(scan_ms, 4),
-                 "sharded_world1_step_ms": round(sharded_ms, 4),
+    res[mode] = {"search_device_ms": round(local_ms, 4), "search_deferred_ms": round(deferred_ms, 4),
+                 "scan_kernel_ms": round(scan_ms, 4),
+                 "search_tensors_ms": round(sync_ms, 4), "pipelined_submit_collect_ms": round(pipe_ms, 4),
+                 "leader_search_ms": round(lead_ms, 4), "leader_search_p50_ms": round(lead_p50, 4),
+                 "leader_search_p95_ms": round(lead_p95, 4), "rag_index_search_host_ms": round(host_ms, 4),
                  "scan_GBps": round((4.0 if mode == "one_pass" else 2.0) * rows * d / (scan_ms * 1e-3) / 1e9, 1),
-                 "sharded_equals_local": same,
+                 "sharded_equals_local": same, "leader_equals_local": lead_same,
                  "identical_to_one_pass": bool(np.array_equal(ids, ref[0]) and np.array_equal(sc.view(np.uint32), ref[1].view(np.uint32)))}
 if idx.screening == SCREEN_FP16:
     res["two_stage"]["fallbacks"] = idx.screen_stats()["fallbacks"]
+    res["two_stage"]["repeats_through_fp32"] = sh.repeats
 print(json.dumps(res), flush=True)
 dist.destroy_process_group()

@@ -42,7 +42,7 @@ def main() -> None:
         out_s.copy_(torch.from_numpy(D))
         out_i.copy_(torch.from_numpy(I))
 
-    link = ShardedFlatIndex(OracleLocal(), 0, device="cpu", merge=merge)
+    link = ShardedFlatIndex(OracleLocal(), 0, device="cpu", merge=merge, dim=d)
 
     class StubModel:  # score = 1 / (1 + tokens in the pair): deterministic, batch-shape independent
         class cfg:

@@ -38,7 +38,7 @@ def main() -> None:
     X_local = oracle.synth_rows(1234, lo, hi - lo, d)
     Q = oracle.synth_rows(4321, 0, nq, d)
 
-    if mode == "cpu":
+    if mode in ("cpu", "cpuflag"):
         class OracleLocal:
             def search_device(self, q_ptr, nq_, k_, s_ptr, i_ptr, stream=0):
                 q = np.ctypeslib.as_array(ctypes.cast(q_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, d))
@@ -51,7 +51,25 @@ def main() -> None:
             out_s.copy_(torch.from_numpy(D))
             out_i.copy_(torch.from_numpy(I))
 
-        sharded = ShardedFlatIndex(OracleLocal(), metric, device="cpu", merge=merge)
+        class FlaggingLocal(OracleLocal):
+            """A local index with the two-stage choice (rag_index_search_device_ex's contract): in
+            RAG_SEARCH_DEFER_FALLBACK mode the LAST rank's first two searches report "not final" and leave
+            garbage in the lists; RAG_SEARCH_EXACT_ONE_PASS returns the truth and clears the word."""
+            deferred_calls = 0
+
+            def search_device_ex(self, q_ptr, nq_, k_, s_ptr, i_ptr, mode_, flag_ptr, stream=0):
+                flag = np.ctypeslib.as_array(ctypes.cast(flag_ptr, ctypes.POINTER(ctypes.c_uint32)), (1,))
+                self.search_device(q_ptr, nq_, k_, s_ptr, i_ptr)
+                flag[0] = 0
+                if mode_ == 2:  # SEARCH_DEFER_FALLBACK
+                    self.deferred_calls += 1
+                    if rank == world - 1 and self.deferred_calls <= 2:
+                        np.ctypeslib.as_array(ctypes.cast(i_ptr, ctypes.POINTER(ctypes.c_int64)), (nq_, k_))[:] = 7
+                        np.ctypeslib.as_array(ctypes.cast(s_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, k_))[:] = 1e30
+                        flag[0] = 1
+
+        local = FlaggingLocal() if mode == "cpuflag" else OracleLocal()
+        sharded = ShardedFlatIndex(local, metric, device="cpu", merge=merge, dim=d)
     else:
         from rag_inference_pipeline_amd.flat_index import FlatIndex
 
@@ -63,9 +81,19 @@ def main() -> None:
         sharded = ShardedFlatIndex(local, metric, device=dev)
         assert sharded.backend == ("nccl" if mode == "nccl" else "gloo"), sharded.backend
 
+    extra = {}
+    if mode == "cpuflag":
+        # two searches in flight (submit / collect), both flagged by the last rank: each is repeated through the
+        # "fp32 scan" on EVERY rank (the flag is the same word everywhere) and comes out right
+        Qa, Qb = torch.from_numpy(Q.copy()), torch.from_numpy(Q[::-1].copy())
+        ta, tb = sharded.submit(Qa, k), sharded.submit(Qb, k)
+        sa, ia = (t.clone() for t in sharded.collect(ta))
+        sb, ib = (t.clone() for t in sharded.collect(tb))
+        extra = dict(Da=sa.numpy(), Ia=ia.numpy(), Db=sb.numpy(), Ib=ib.numpy(), repeats_pipelined=sharded.repeats)
     D, I = sharded.search(Q, k)
     D2, I2 = sharded.search(Q[: max(1, nq // 2)], k)  # a second shape re-uses the group
-    extra = {}
+    if mode == "cpuflag":
+        extra["repeats_total"] = sharded.repeats
     if mode == "nccl":  # the serving protocol over RCCL: control words and the batch travel on the device
         if rank == 0:
             D3, I3 = sharded.leader_search(Q, k)

@@ -71,6 +71,35 @@ def test_cross_encoder_bert_head_scores_and_order(gpu_required):
     model.close()
 
 
+@pytest.mark.parametrize("nseq,lo,hi", [(24, 8, 21), (40, 30, 61)])   # T ~ 350 (fp32 MFMA everywhere) and ~ 1800 (split-bf16 for T rows)
+def test_first_token_last_layer_matches_the_full_pass(gpu_required, nseq, lo, hi):
+    """CLS pooling and the classifier head run the last layer on first tokens only (rag_bert.hip: last_first_only).
+    Those nseq rows go through GEMM kernels / split-K counts picked for nseq rows, the full pass (hidden_states)
+    through the ones picked for T rows — different summation orders on either side of the 1024-row switch, the
+    same values to fp32 rounding."""
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    cfg.pooling = "cls"
+    w = random_weights(cfg, 5)
+    model = BertModel(cfg, w)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(lo, hi, size=nseq)
+    seqs = _seqs(rng, lens, cfg.vocab_size)
+    types = [[0] * 4 + [1] * (len(s) - 4) for s in seqs]
+    T = int(lens.sum())
+    assert (T > 1024) == (lo >= 30)
+    first = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    full = model.hidden_states(seqs, types)[first]                     # the full pass, then first-token rows
+    cls = model.embed(seqs, types, normalize=False, pooling="cls")     # the compact path
+    np.testing.assert_allclose(cls, full, atol=2e-5, rtol=1e-5)
+    unit = model.embed(seqs, types, normalize=True, pooling="cls")
+    np.testing.assert_allclose(unit, full / np.linalg.norm(full, axis=1, keepdims=True), atol=1e-5)
+    logits = model.classify(seqs, types, sigmoid=False)[:, 0]          # compact path + head
+    pooled = np.tanh(full.astype(np.float64) @ w["head_dense_w"].astype(np.float64).T + w["head_dense_b"])
+    want = pooled @ w["head_out_w"].astype(np.float64).T + w["head_out_b"]
+    np.testing.assert_allclose(logits, want[:, 0], atol=1e-5, rtol=1e-5)
+    model.close()
+
+
 def test_xlm_roberta_head_and_position_offset_long_sequences(gpu_required):
     cfg = BertConfig(vocab_size=3000, hidden=768, n_layers=2, n_heads=12, intermediate=3072, max_positions=514,
                      type_vocab=1, pos_offset=2, head="roberta", n_labels=1, ln_eps=1e-5)

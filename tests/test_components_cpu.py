@@ -174,3 +174,16 @@ def test_fast_constructor_builds_what_validation_builds():
     item = RetrievalResponseItem(request_id="r", docs=[fast_constructor(RetrievalDocument)(
         doc_id=1, title="", content="", category="", score=1.0)], compressed_docs=None)
     assert item.docs[0].doc_id == 1 and '"score":1.0' in item.model_dump_json()
+
+
+def test_build_index_does_not_take_torchruns_default_run_id_as_a_build_id(monkeypatch, tmp_path):
+    """torchrun's static rendezvous exports TORCHELASTIC_RUN_ID=none for EVERY run: accepted as a build id it
+    would make the .done markers of a crashed earlier build indistinguishable from this build's."""
+    from rag_inference_pipeline_amd.tools.build_index import build_index
+
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    with pytest.raises(ValueError, match="build id"):
+        build_index(str(tmp_path), "synthetic:all-MiniLM-L6-v2", str(tmp_path / "x.f32"), rank=1, world=2)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-4711")   # a real id is used: the call gets past the check
+    with pytest.raises(FileNotFoundError, match="Document database"):
+        build_index(str(tmp_path), "synthetic:all-MiniLM-L6-v2", str(tmp_path / "x.f32"), rank=1, world=2)

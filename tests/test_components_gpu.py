@@ -167,6 +167,53 @@ def test_embedding_generator_from_local_checkpoint_matches_transformers(gpu_requ
     assert not gen.is_loaded
 
 
+def test_embedder_hands_its_batch_to_the_index_in_device_memory(gpu_required, corpus):
+    """encode_device() -> FAISSStore.search: the embeddings stay in HBM, the search runs on the encoder's stream,
+    ids and score bits equal encode() -> search() (and so the oracle); concurrent batches on pool threads — the
+    scheduler's situation — do not mix their embeddings up."""
+    import threading
+    from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+    from rag_inference_pipeline_amd.device_embeddings import DeviceEmbeddings
+    X, path = corpus
+    settings = PipelineSettings(FAISS_INDEX_PATH=str(path), faiss_dim=384, embedding_model_name="synthetic:all-MiniLM-L6-v2",
+                                DISABLE_CACHE_FOR_PROFILING="true")
+    store, gen = FAISSStore(settings), EmbeddingGenerator(settings)
+    store.load(); gen.load()
+    texts = [f"query number {i} about topic {i % 7} and some more words" for i in range(32)]
+    host = gen.encode(texts)
+    dev = gen.encode_device(texts)
+    assert isinstance(dev, DeviceEmbeddings) and dev.shape == (32, 384) and dev.ndim == 2
+    np.testing.assert_array_equal(dev.numpy().view(np.uint32), host.view(np.uint32))   # the same forward pass
+    D1, I1 = store.search(host, 10)
+    D2, I2 = store.search(gen.encode_device(texts), 10)
+    Do, Io = oracle.search(X, host, 10)
+    for D, I in ((D1, I1), (D2, I2)):
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    with pytest.raises(ValueError, match="dimension mismatch"):
+        store.search(DeviceEmbeddings(dev._tensor[:, :100].contiguous(), dev.stream, dev.device), 10)
+    errors = []
+
+    def client(t):
+        try:
+            mine = [f"thread {t} text {i} {'word ' * (i % 5)}" for i in range(8 + t)]
+            want = oracle.search(X, gen.encode(mine), 10)
+            for _ in range(5):
+                D, I = store.search(gen.encode_device(mine), 10)
+                if not (np.array_equal(I, want[1]) and np.array_equal(D.view(np.uint32), want[0].view(np.uint32))):
+                    errors.append(f"thread {t}: results differ")
+        except Exception as exc:  # noqa: BLE001
+            errors.append(f"thread {t}: {type(exc).__name__}: {exc}")
+
+    pool = [threading.Thread(target=client, args=(t,)) for t in range(4)]
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    assert not errors, errors
+    gen.unload(); store.unload()
+
+
 def test_reranker_from_local_checkpoint_matches_transformers(gpu_required, tmp_path):
     import torch
     from rag_inference_pipeline_amd.components.reranker import Reranker

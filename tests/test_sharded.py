@@ -62,14 +62,33 @@ def test_shard_ranges_partition_the_corpus():
         assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
         sizes = [hi - lo for lo, hi in edges]
         assert max(sizes) - min(sizes) <= 1
-    assert pack_layout(32, 10) == (2560, 3840)  # 3.84 KB per rank per batch
-    assert pack_layout(1, 1) == (8, 16) and pack_layout(3, 5)[1] % 8 == 0
+    # 3.84 KB of ids and scores per rank per batch + the "not final" word, padded to 8 bytes
+    assert pack_layout(32, 10) == (2560, 3840, 3848)
+    assert pack_layout(1, 1) == (8, 12, 16) and pack_layout(3, 5)[2] % 8 == 0
 
 
 @pytest.mark.parametrize("world,metric", [(2, 0), (3, 1)])
 def test_sharded_search_gloo_cpu_rehearsal(tmp_path, world, metric):
     n, d, nq, k = 5001, 64, 9, 10
     _check(_launch("cpu", world, tmp_path, n, d, nq, k, metric), n, d, nq, k, metric, world)
+
+
+def test_flagged_batches_are_repeated_through_the_exact_scan_on_every_rank(tmp_path):
+    """The "not final" word of a rank's deferred two-stage search travels in the all-gather: when the last rank
+    raises it, every rank sees the same OR-ed word, repeats the batch in RAG_SEARCH_EXACT_ONE_PASS mode and
+    gathers again — with two searches in flight (submit / collect) as well as one at a time."""
+    world, n, d, nq, k, metric = 3, 4001, 48, 7, 10, 0
+    results = _launch("cpuflag", world, tmp_path, n, d, nq, k, metric)
+    _check(results, n, d, nq, k, metric, world)   # the later, unflagged searches
+    X, Q = oracle.synth_rows(1234, 0, n, d), oracle.synth_rows(4321, 0, nq, d)
+    Da, Ia = oracle.search(X, Q, k, metric)
+    Db, Ib = oracle.search(X, Q[::-1].copy(), k, metric)
+    for res in results:
+        np.testing.assert_array_equal(res["Ia"], Ia)
+        np.testing.assert_array_equal(res["Da"], Da)
+        np.testing.assert_array_equal(res["Ib"], Ib)
+        np.testing.assert_array_equal(res["Db"], Db)
+        assert int(res["repeats_pipelined"]) == 2 and int(res["repeats_total"]) == 2   # exactly the flagged ones
 
 
 def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
