@@ -256,12 +256,18 @@ typedef struct rag_bert_config {
     int32_t gemm_mode;     /* RAG_GEMM_*: how big-batch (> 1024 tokens) GEMMs run */
 } rag_bert_config;
 
-/* RAG_GEMM_F32 (default): fp32 results.  Big-batch GEMMs run on the bf16 matrix cores with every fp32
- *   operand split exactly into three bf16 terms and the six products of weight >= 2^-16 accumulated in
- *   fp32 (error below the fp32 accumulation's own rounding; 2.7x the fp32 MFMA rate).  The library
- *   builds the split weight images at rag_bert_create (+1.5x the GEMM weights' memory).
- * RAG_GEMM_F16: big-batch GEMMs take fp16 inputs (fp32 accumulate) — the precision the reference runs
- *   its reranker at on a GPU (reranker.py:91-93); the caller supplies fp16 weight copies.
+/* RAG_GEMM_F32 (default): fp32 results.  Big-batch GEMMs run on the fp16 matrix cores with every fp32 operand
+ *   written as TWO fp16 numbers — hi = fp16(x), lo = fp16((x - hi) 2^11): 22 significand bits — and the three products
+ *   hi hi, lo hi, hi lo accumulated in fp32 (the cross terms in their own accumulator, scaled by 2^-11 at the end): the
+ *   error stays below the fp32 accumulation's own rounding (measured against float64: at or below the fp32-MFMA
+ *   path's), at 5x the fp32 MFMA rate.  fp16's exponent range is narrower than fp32's: a pass in which an activation
+ *   reaches |x| >= 65504 raises a flag on the device, and the host-pointer entry point then repeats that pass with
+ *   every operand split exactly into three bf16 numbers (six products; fp32's range; built on first need) — so results
+ *   never depend on the range, only the time does (rag_bert_range_events counts such passes).  A checkpoint with a
+ *   GEMM weight outside fp16's range uses the three-plane path throughout.  The library builds the split weight
+ *   images at rag_bert_create (+1x the GEMM weights' memory).
+ * RAG_GEMM_F16: big-batch GEMMs take fp16 inputs (fp32 accumulate) — the precision the reference runs its reranker
+ *   at on a GPU (reranker.py:91-93); the library builds the fp16 weight image itself.
  * RAG_GEMM_F32_STRICT: every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32 chains). */
 #define RAG_GEMM_F32 0
 #define RAG_GEMM_F16 1
@@ -274,7 +280,6 @@ typedef struct rag_bert_config {
  *     qkv_w [3H][H] (q;k;v rows) qkv_b [3H]  attn_out_w [H][H] attn_out_b [H]  ln1_gamma ln1_beta
  *     ffn_in_w [I][H] ffn_in_b [I]  ffn_out_w [H][I] ffn_out_b [H]  ln2_gamma ln2_beta
  *   then, if head != RAG_HEAD_NONE: head_dense_w [H][H] head_dense_b [H] head_out_w [n_labels][H] head_out_b
- *   then, if gemm_mode == RAG_GEMM_F16: per layer 4 fp16 copies (qkv_w, attn_out_w, ffn_in_w, ffn_out_w), same shapes
  * All fp32, torch.nn.Linear layout (W[out][in], row-major), device memory on `device`.  The library
  * does not copy them: the caller (PyTorch-ROCm tensors) keeps them alive until rag_bert_destroy. */
 int32_t rag_bert_weight_count(const rag_bert_config* cfg);
@@ -296,6 +301,12 @@ int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* 
                             const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
                             int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
                             void* stream);
+
+/* Passes the host-pointer entry point has repeated on the three-plane path because an activation left fp16's range
+ * (RAG_GEMM_F32, see above).  `pending` (may be NULL; synchronises the device when given): 1 when a pass of one of the
+ * ASYNCHRONOUS entry points (rag_bert_forward_device / _to_device) has raised the flag since it was last taken — those
+ * cannot repeat a pass themselves, their caller must (taking the flag clears it). */
+int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pending);
 
 /* Token ids in HOST memory, result left in DEVICE memory: the hand-off from the embedder to the index inside a
  * retrieval batch (services/retrieval/api.py:351-390 passes a host array between them; here the embeddings stay

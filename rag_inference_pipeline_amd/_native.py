@@ -18,7 +18,8 @@ _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
 _SOURCES = ["rag_amd.hip", "rag_bert.hip", "rag_lz4.cpp"]
-_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "rag_common.h", "rag_lz4.cpp"]
+_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "gemm_wl.hip.h", "rag_common.h",
+         "rag_lz4.cpp"]
 
 RAG_OK = 0
 RAG_ERR_INVALID_ARG = 1
@@ -136,6 +137,7 @@ def _declare(lib: C.CDLL) -> None:
                                       C.POINTER(vp)]),
         "rag_bert_destroy": (C.c_int, [vp]),
         "rag_bert_forward": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, f32p]),
+        "rag_bert_range_events": (C.c_int, [vp, i64p, i32p]),
         "rag_bert_forward_to_device": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, vp,
                                                  C.POINTER(vp)]),
         "rag_bert_forward_device": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

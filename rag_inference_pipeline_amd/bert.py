@@ -252,13 +252,7 @@ class BertModel:
         if cfg.head != "none":
             order += list(HEAD_KEYS)
         ptrs = [self._tensors[k].data_ptr() if k in self._tensors else 0 for k in order]
-        if cfg.gemm_dtype == "f16":  # fp16 copies of the four GEMM weights of every layer
-            for l in range(cfg.n_layers):
-                for k in ("qkv_w", "attn_out_w", "ffn_in_w", "ffn_out_w"):
-                    t16 = self._tensors[f"layer{l}.{k}"].to(torch.float16).contiguous()
-                    self._tensors[f"layer{l}.{k}.f16"] = t16
-                    ptrs.append(t16.data_ptr())
-        elif cfg.gemm_dtype not in _GEMM_MODES:
+        if cfg.gemm_dtype not in _GEMM_MODES:
             raise ValueError(f"gemm_dtype must be one of {sorted(_GEMM_MODES)}, got {cfg.gemm_dtype!r}")
         table = (C.c_void_p * len(ptrs))(*ptrs)
         struct = cfg.to_struct()
@@ -310,6 +304,13 @@ class BertModel:
             self._h, C.c_void_p(ids_ptr), C.c_void_p(types_ptr or None), C.c_void_p(cu_ptr), int(nseq),
             int(total_tokens), int(max_seq_len), int(out_kind), 1 if normalize else 0, C.c_void_p(out_ptr),
             C.c_void_p(stream)))
+
+    def range_events(self, take_pending: bool = False) -> tuple[int, bool]:
+        """(forward passes repeated on the three-plane bf16 path because an activation left fp16's range, whether an
+        asynchronous pass has raised the flag since it was last taken) — rag_bert_range_events."""
+        n, pend = C.c_int64(0), C.c_int32(0)
+        _native.check(self._lib.rag_bert_range_events(self._h, C.byref(n), C.byref(pend) if take_pending else None))
+        return int(n.value), bool(pend.value)
 
     def embed_to_device(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None,
                         normalize: bool = True, pooling: str | None = None):

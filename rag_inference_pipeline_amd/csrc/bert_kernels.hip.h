@@ -1151,3 +1151,5 @@ __global__ __launch_bounds__(64) void head_out_kernel(const float* x, const floa
 }
 
 }  // namespace ragb
+
+#include "gemm_wl.hip.h"  // big-batch GEMM with both operands through LDS-DMA (uses the types and helpers above)

@@ -1,0 +1,682 @@
+// gemm_wl.hip.h — big-batch GEMM of the transformer layers, both operands through LDS-DMA.
+//
+//   C[M][N] = A[M][K] · W[N][K]ᵀ (+ bias[N]) (activation) (+ R[M][N]),   A, C, R fp32 in memory
+//
+// Replaces gemm_nt_x6_kernel / gemm_nt_f16_kernel (bert_kernels.hip.h) for M > 1024 — the cross-encoder's
+// GEMMs (reference src/pipeline/components/reranker.py:248-252: model(**inputs) over all (query, doc) pairs of a batch).
+// Same arithmetic, same summation order per output element, so the results are bit-identical to those kernels;
+// what changes is how the operands reach the matrix cores.
+//
+// What bounded the old kernels (41 % MFMA utilisation, ablations and cycle stamps): operand
+// delivery.  A went global -> VGPR -> split (VALU) -> LDS (ds_write, the slow LDS path) and was read back by the two
+// waves that share its rows; W fragments went L2 -> VGPR in every one of the two waves that share them; eight waves
+// with 16-20 KB of loads in flight each are at the edge of what a CU needs (~160 KB) to cover L2/HBM latency.  Here:
+//
+//   * BOTH operands arrive by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write, no VALU on the way
+//     in, and — with no ordinary register load in the K loop — hipcc leaves the DMA ring alone (it would drain it with
+//     a vmcnt(0) at every use of a plain load).  A ring of NS stages keeps NS - 1 stages in flight or landed.
+//   * A wave owns 32 token ROWS x all 128 columns of the 128 x 128 tile.  Its A rows are loaded by itself, read by
+//     itself and split (fp32 -> three bf16 planes) in ITS registers: no other wave repeats that work, and A needs no
+//     cross-wave synchronisation at all.  A's LDS image is the raw fp32 K-slice, 64 bytes per row, 16-byte chunks
+//     XOR-swizzled by (row >> 2) & 3 on the DMA's source side so that the fragment reads (32 bytes per lane, lane =
+//     row) are bank-conflict free.
+//   * W is stored once, at model creation, in MFMA-fragment order (pack_x6_kernel / pack_f16_frag_kernel): a fragment
+//     is 1 KiB, lane-linear — exactly the shape an LDS-DMA instruction writes — and is read back with one
+//     conflict-free ds_read_b128 per lane.  The four waves share the tile's W fragments through LDS instead of each
+//     pulling them from L2.
+//   * one raw s_barrier per stage; the wait in front of it is a COUNTED vmcnt that leaves the younger stages in flight.
+//
+// MODE 0 (RAG_GEMM_F32): every fp32 operand is the exact sum of three bf16 numbers; the six products of weight
+//   >= 2^-16 go through v_mfma_f32_32x32x16_bf16 (see gemm_nt_x6_kernel for the error analysis).
+// MODE 2 (experiment, scripts/exp/gemm_wl_bench.hip): every fp32 operand as TWO fp16 numbers, hi = fp16(x) and
+//   lo = fp16((x - hi) 2^11) — 22 significand bits — and the three products hi hi, lo hi, hi lo on
+//   v_mfma_f32_32x32x16_f16 (the cross terms in an accumulator of their own, scaled by 2^-11 at the end): half the
+//   MFMAs and two thirds of the operand bytes of MODE 0, relative error ~2^-22 per operand instead of ~2^-24, and
+//   fp16's range (|x| < 65504) instead of fp32's.
+// MODE 1 (RAG_GEMM_F16): A rounded to fp16 on the way to the matrix core, W an fp16 image, one
+//   v_mfma_f32_32x32x16_f16 per fragment pair — the precision the reference runs its reranker at on a GPU
+//   (reranker.py:91-93).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ragb {
+
+struct GemmWlParams {
+    const float* A;      // [M][lda] fp32
+    const void* Wimg;    // fragment-order image: MODE 0 three bf16 planes (pack_x6_kernel), MODE 1 one fp16 plane
+    const float* bias;   // [N] or null
+    const float* R;      // [M][ldr] residual or null
+    float* C;            // [M][ldc]
+    int M, N, K;         // N % 32 == 0, K % (16 KS) == 0
+    int lda, ldr, ldc;
+    int act;
+    uint32_t* range_flag;  // MODE 2: set to 1 when an element of A is outside fp16's range (|x| >= 65504); may be null
+};
+
+// W fp32 [N][K] -> fp16 image in MFMA-fragment order: fragment (nt, ks) holds, for lane (r, h), the eight values
+// W[32 nt + r][16 ks + 8 h ..] at ((nt * K/16 + ks) * 64 + 32 h + r) * 8.
+__global__ void pack_f16_frag_kernel(const float* W, int N, int K, int ldw, _Float16* out) {  // N % 32 == 0, K % 16 == 0
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
+    const int nt = n >> 5, r = n & 31, ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    out[(((size_t)nt * (K / 16) + ks) * 64 + 32 * h + r) * 8 + j] = (_Float16)W[(size_t)n * ldw + k];
+}
+
+// W fp32 [N][K] -> TWO fp16 planes in MFMA-fragment order (MODE 2): hi = fp16(w), lo = fp16((w - hi) * 2^11); fragment
+// (nt, ks, plane) at ((nt * K/16 + ks) * 2 + plane) * 512 halves, lane (r, h)'s eight values at (32 h + r) * 8.
+constexpr float kX3Scale = 2048.0f;        // 2^11: the low plane is stored scaled so that it stays in fp16's normal range
+constexpr float kX3Unscale = 1.0f / 2048.0f;
+constexpr float kF16Max = 65504.0f;
+__global__ void pack_f16x2_frag_kernel(const float* W, int N, int K, int ldw, _Float16* out, uint32_t* range_flag) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * K) return;
+    const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
+    const int nt = n >> 5, r = n & 31, ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
+    const float x = W[(size_t)n * ldw + k];
+    if (range_flag && fabsf(x) >= kF16Max) *range_flag = 1u;   // (inf / huge: the caller keeps the split-bf16 image)
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)((x - (float)hi) * kX3Scale);
+    const size_t frag = ((size_t)nt * (K / 16) + ks) * 2;
+    const size_t lane_off = (size_t)(32 * h + r) * 8 + j;
+    out[(frag + 0) * 512 + lane_off] = hi;
+    out[(frag + 1) * 512 + lane_off] = lo;
+}
+
+#if defined(RAGB_WL_NO_MFMA)   // experiment builds only (scripts/exp/gemm_wl_bench.hip)
+#define RAGB_WL_MFMA_BF16(w, a, c) ([&] { asm volatile("" ::"v"(w), "v"(a)); return c; }())
+#define RAGB_WL_MFMA_F16(w, a, c) ([&] { asm volatile("" ::"v"(w), "v"(a)); return c; }())
+#else
+#define RAGB_WL_MFMA_BF16(w, a, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0)
+#define RAGB_WL_MFMA_F16(w, a, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, c, 0, 0, 0)
+#endif
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes, each lane's own global address -> LDS at `lds` + 16 * lane
+// (`lds` must be wave-uniform).  (A helper, not a lambda: a lambda returning an address-space-qualified pointer
+// silently drops the kernel's host stub under hipcc 7.2.)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+
+template <int MODE, int KS, int NS>
+struct WlGeom {
+    static constexpr int PL = MODE == 0 ? 3 : (MODE == 2 ? 2 : 1);   // W planes
+    static constexpr int A_STAGE = KS * 128 * 64;             // bytes: KS K-steps x 128 rows x 16 fp32
+    static constexpr int W_STAGE = 4 * KS * PL * 1024;        // bytes: 4 column tiles x KS x PL fragments of 1 KiB
+    static constexpr int STAGE = A_STAGE + W_STAGE;
+    static constexpr int RING = NS * STAGE;
+    static constexpr int EPI = 4 * 16 * 132 * 4;              // epilogue: per wave 16 rows x 132 floats
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static constexpr int G = 2 * KS + KS * PL;                // LDS-DMA instructions per wave per stage
+};
+
+// Epilogue of the LDS-DMA GEMMs.  Lane (r, h) holds, for its token row, features 32 b + 8 g + 4 h + 0..3 in
+// acc[b][4g..4g+3].  Each wave transposes its own 32 x 128 tile through its own 16-row LDS strip (no cross-wave
+// traffic, so no barrier: a wave's LDS operations execute in order), two halves of 16 rows; every store instruction
+// then writes two complete 512-byte rows, and bias / activation / residual are applied on that side (coalesced too).
+// The caller has passed a barrier since the last read of the ring, which this reuses.
+__device__ __forceinline__ void wl_epilogue(const GemmWlParams& p, const f32x16 (&acc)[4], char* smem, int m0, int n0,
+                                            int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    float* Cs = reinterpret_cast<float*>(smem) + wave * 16 * 132;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if ((r >> 4) == hh) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(&Cs[(r & 15) * 132 + b * 32 + 8 * g + 4 * h]) = v;
+                }
+        }
+        const int c4 = lane & 31;
+        const int n = n0 + 4 * c4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && n < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = (lane >> 5) + 2 * i;                       // row of the strip
+            const int m = m0 + wave * 32 + hh * 16 + lr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lr * 132 + 4 * c4]);
+            if (m < p.M && n < p.N) {                                  // N % 32 == 0: a float4 is inside or outside
+                v += bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+                if (p.R) v += *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+#if defined(RAGB_WL_NO_STORE)   // experiment build: keep the values live, skip the store
+                if (v[0] == 12345.678f) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+#else
+                *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+#endif
+            }
+        }
+    }
+}
+
+// fp32 -> the three bf16 planes of the exact split (hi, mid, lo), eight values of a lane's fragment
+__device__ __forceinline__ void wl_split3(const f32x4 x0, const f32x4 x1, bf16x8 (&af)[3]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+#if defined(RAGB_WL_NO_SPLIT)   // experiment build: no split arithmetic (wrong values, same data flow)
+        af[0][e] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(x) >> 16));
+        af[1][e] = af[0][e];
+        af[2][e] = af[0][e];
+#else
+        const __bf16 hi = (__bf16)x;
+        const float r1 = x - (float)hi;
+        const __bf16 mid = (__bf16)r1;
+        af[0][e] = hi;
+        af[1][e] = mid;
+        af[2][e] = (__bf16)(r1 - (float)mid);
+#endif
+    }
+}
+
+// PIPE (KS == 1 only): the A fragment of stage st + 1 is read and converted DURING stage st's MFMAs — its rows are this
+// wave's own, so a counted vmcnt of its own is all the synchronisation that read needs — instead of in front of its
+// own stage's MFMAs, where nothing of this wave's covers the ~50 conversion instructions.
+template <int MODE, int KS, int NS, bool PIPE = false>
+__global__ __launch_bounds__(256, 2) void gemm_nt_wl_kernel(const GemmWlParams p) {
+    using Geo = WlGeom<MODE, KS, NS>;
+    constexpr int PL = Geo::PL;
+    static_assert(NS >= 3, "the ring needs a stage in flight beside the one being read and the one being refilled");
+    static_assert(!PIPE || KS == 1, "the pipelined form keeps one K-step's A fragment in registers");
+    static_assert(!PIPE || MODE != 2, "MODE 2 has no pipelined form");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ALL of the kernel's LDS (a second object beside a
+                                                                  // DMA-filled array makes hipcc drain the ring)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!xcd_tile(p.M, p.N, 128, 128, m0, n0)) return;
+    const int nks = p.K / 16;
+    const int n_stages = nks / KS;
+
+    // ---- LDS-DMA sources.  A: instruction q of a stage covers K-step q / 2 ... for THIS wave's 32 rows: two
+    // instructions of 16 rows x 64 bytes per K-step; lane l -> row 16 q' + l / 4, LDS slot l % 4, source chunk
+    // slot ^ ((row >> 2) & 3).  W: this wave brings column tile `wave` of the workgroup's four.
+    const char* a_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2);          // row of the tile
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;                               // rows past M: valid memory, results dropped
+        a_src[q] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16;
+    }
+    int nt_w = (n0 >> 5) + wave;
+    nt_w = nt_w < (p.N >> 5) ? nt_w : (p.N >> 5) - 1;
+    const char* w_src = static_cast<const char*>(p.Wimg) + (size_t)nt_w * nks * PL * 1024 + lane * 16;
+
+    auto issue_stage = [&](int st) {   // stage number st (clamped by the caller) into slot st % NS
+        char* slot = smem + (st % NS) * Geo::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const size_t koff = (size_t)(st * KS + ks) * 64;       // bytes along K in a row of A
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                glds16(a_src[q] + koff, slot + ks * 8192 + (wave * 32 + q * 16) * 64);
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+                glds16(w_src + ((size_t)(st * KS + ks) * PL + pl) * 1024,
+                       slot + Geo::A_STAGE + ((wave * KS + ks) * PL + pl) * 1024);
+        }
+    };
+
+    f32x16 acc[4];
+    f32x16 accx[MODE == 2 ? 4 : 1];   // MODE 2: the cross terms (scaled by 2^11)
+    float amax = 0.f;                 // MODE 2: largest |a| this lane has converted
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+    for (int b = 0; b < (MODE == 2 ? 4 : 1); ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accx[b][i] = 0.f;
+
+    // this lane's two 16-byte chunks of its row's K-slice: chunks 2h and 2h + 1, swizzled
+    const int my_row = wave * 32 + r;
+    const int sw = (my_row >> 2) & 3;
+    const int a_off0 = my_row * 64 + (((2 * h) ^ sw) << 4), a_off1 = my_row * 64 + (((2 * h + 1) ^ sw) << 4);
+
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue_stage(st < n_stages ? st : n_stages - 1);
+
+    // (W plane, A plane) of the six kept terms, smallest first — the order gemm_nt_x6_kernel adds them in
+    constexpr int kTerm[6][2] = {{0, 2}, {2, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+
+    auto wait_stages_in_flight = [&]() {   // own DMAs of all but the NS - 2 youngest stages have landed
+        if constexpr (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo::G) : "memory");
+        else if constexpr (NS == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Geo::G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * Geo::G) : "memory");
+    };
+    if constexpr (!PIPE) {
+        for (int st = 0; st < n_stages; ++st) {
+            // own parts of stage st have landed once at most the NS - 2 younger stages' DMAs are outstanding ...
+            wait_stages_in_flight();
+            // ... and after the barrier everybody's have; every wave has also finished reading stage st - 1 (its MFMAs
+            // consumed those registers), so that slot may be refilled
+            __builtin_amdgcn_s_barrier();
+            {
+                const int nx = st + NS - 1;
+                issue_stage(nx < n_stages ? nx : n_stages - 1);   // past the end: a harmless re-load keeps the counts fixed
+            }
+            const char* slot = smem + (st % NS) * Geo::STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(slot + ks * 8192 + a_off0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(slot + ks * 8192 + a_off1);
+                const char* wbase = slot + Geo::A_STAGE + ks * PL * 1024 + lane * 16;
+                if constexpr (MODE == 0) {
+                    bf16x8 af[3];
+                    wl_split3(x0, x1, af);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        bf16x8 wf[3];
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wf[pl] = *reinterpret_cast<const bf16x8*>(wbase + (b * KS * PL + pl) * 1024);
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) acc[b] = RAGB_WL_MFMA_BF16(wf[kTerm[t][0]], af[kTerm[t][1]], acc[b]);
+                    }
+                } else if constexpr (MODE == 2) {
+                    f16x8 ah, al;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = e < 4 ? x0[e] : x1[e - 4];
+                        const _Float16 hi = (_Float16)x;
+                        ah[e] = hi;
+                        al[e] = (_Float16)((x - (float)hi) * kX3Scale);
+                        amax = fmaxf(amax, fabsf(x));   // NaN never wins: a NaN input gives a NaN output, as in fp32
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const f16x8 wh = *reinterpret_cast<const f16x8*>(wbase + (b * KS * PL + 0) * 1024);
+                        const f16x8 wl = *reinterpret_cast<const f16x8*>(wbase + (b * KS * PL + 1) * 1024);
+                        acc[b] = RAGB_WL_MFMA_F16(wh, ah, acc[b]);
+                        accx[b] = RAGB_WL_MFMA_F16(wl, ah, accx[b]);
+                        accx[b] = RAGB_WL_MFMA_F16(wh, al, accx[b]);
+                    }
+                } else {
+                    f16x8 af;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[e] = (_Float16)(e < 4 ? x0[e] : x1[e - 4]);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const f16x8 wf = *reinterpret_cast<const f16x8*>(wbase + (b * KS * PL) * 1024);
+                        acc[b] = RAGB_WL_MFMA_F16(wf, af, acc[b]);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == 2) {   // the cross terms carry the low planes' 2^11
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[b][i] = __builtin_fmaf(accx[b][i], kX3Unscale, acc[b][i]);
+            // a value fp16 cannot hold became inf in the high plane: tell the host, which repeats the pass on the
+            // split-bf16 path (fp32's exponent range)
+            if (p.range_flag && amax >= kF16Max) *p.range_flag = 1u;
+        }
+    } else {
+        // own A rows of stage 0: every DMA issued so far except the ones behind them
+        bf16x8 af[3];
+        f16x8 ah;
+        auto take_a = [&](int st) {   // A fragment of stage st from its slot -> af / ah
+            const char* slot = smem + (st % NS) * Geo::STAGE;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(slot + a_off0);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(slot + a_off1);
+            if constexpr (MODE == 0) {
+                wl_split3(x0, x1, af);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ah[e] = (_Float16)(e < 4 ? x0[e] : x1[e - 4]);
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * Geo::G - 2) : "memory");
+        take_a(0);
+        for (int st = 0; st < n_stages; ++st) {
+            wait_stages_in_flight();
+            __builtin_amdgcn_s_barrier();
+            {
+                const int nx = st + NS - 1;
+                issue_stage(nx < n_stages ? nx : n_stages - 1);
+            }
+            const char* wbase = smem + (st % NS) * Geo::STAGE + Geo::A_STAGE + lane * 16;
+            if constexpr (MODE == 0) {
+                bf16x8 wf[4][3];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wf[b][pl] = *reinterpret_cast<const bf16x8*>(wbase + (b * PL + pl) * 1024);
+                bf16x8 ac[3] = {af[0], af[1], af[2]};
+                // stage st + 1's A rows (this wave's own DMAs): behind them are its W fragments and the younger stages
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL + (NS - 2) * Geo::G) : "memory");
+                take_a(st + 1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b] = RAGB_WL_MFMA_BF16(wf[b][kTerm[t][0]], ac[kTerm[t][1]], acc[b]);
+            } else {
+                f16x8 wf[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) wf[b] = *reinterpret_cast<const f16x8*>(wbase + b * PL * 1024);
+                const f16x8 ac = ah;
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PL + (NS - 2) * Geo::G) : "memory");
+                take_a(st + 1);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[b] = RAGB_WL_MFMA_F16(wf[b], ac, acc[b]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last stages
+    __builtin_amdgcn_s_barrier();                       // every wave is done with the ring: it carries the output now
+
+    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+}
+
+// ---- role-split rings --------------------------------------------------------------------------------------------
+// What the first form above showed (scripts/exp/gemm_wl_bench.hip, ablation builds): with its MFMAs removed it still
+// took 60 % of its time, and the two did not overlap — every stage waited ~2 us for its DMAs.  A's rows are a first
+// touch of HBM (each 128-row slab is read by the N / 128 workgroups of its row tile at about the same moment: one of
+// them misses, the others queue behind the same miss), W's fragments are L2 hits; but a wave's vmcnt retires IN ORDER,
+// so a wave that issues both waits for the slow one whichever it needs, and a deeper A ring buys nothing.  Here the two
+// streams are issued by DIFFERENT waves: waves 0-1 bring A (64 rows each) into a ring of NA stages, waves 2-3 bring W
+// (two column tiles each) into a ring of NW stages, each with its own counted wait — A can be NA - 1 stages ahead
+// (HBM latency) while W stays NW - 1 ahead (L2 latency) — and one barrier per stage publishes both.  All four waves
+// compute as before: 32 rows x 128 columns each, A fragment from its own rows, split in its own registers.
+template <int MODE, int NA, int NW>
+struct Wl3Geom {
+    static constexpr int PL = MODE == 0 ? 3 : 1;
+    static constexpr int A_STAGE = 128 * 64;                  // one K-step: 128 rows x 16 fp32
+    static constexpr int W_STAGE = 4 * PL * 1024;             // one K-step: 4 column tiles x PL fragments
+    static constexpr int A_RING = NA * A_STAGE;
+    static constexpr int RING = A_RING + NW * W_STAGE;
+    static constexpr int EPI = 4 * 16 * 132 * 4;
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static constexpr int GA = 4;                              // LDS-DMA instructions per A-loader wave per stage
+    static constexpr int GW = 2 * PL;                         // ... per W-loader wave per stage
+};
+
+template <int MODE, int NA, int NW>
+__global__ __launch_bounds__(256, 2) void gemm_nt_wl3_kernel(const GemmWlParams p) {
+    using Geo = Wl3Geom<MODE, NA, NW>;
+    constexpr int PL = Geo::PL;
+    static_assert(NA >= 3 && NW >= 3, "each ring needs a stage in flight beside the one read and the one refilled");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!xcd_tile(p.M, p.N, 128, 128, m0, n0)) return;
+    const int n_stages = p.K / 16;
+    const bool loader_a = wave < 2;   // wave-uniform
+
+    // A-loader wave w: rows 64 w .. 64 w + 63, four instructions of 16 rows; lane l -> row + l / 4, LDS slot l % 4,
+    // source chunk slot ^ ((row >> 2) & 3)
+    const char* a_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave & 1) * 64 + q * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;
+        a_src[q] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16;
+    }
+    // W-loader wave w: column tiles 2 (w - 2) and 2 (w - 2) + 1 of the workgroup's four
+    const char* w_src[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int nt = (n0 >> 5) + (wave & 1) * 2 + j;
+        nt = nt < (p.N >> 5) ? nt : (p.N >> 5) - 1;
+        w_src[j] = static_cast<const char*>(p.Wimg) + (size_t)nt * n_stages * PL * 1024 + lane * 16;
+    }
+    auto issue_a = [&](int st, int slot) {
+        char* dst = smem + slot * Geo::A_STAGE + (wave & 1) * 64 * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) glds16(a_src[q] + (size_t)st * 64, dst + q * 1024);
+    };
+    auto issue_w = [&](int st, int slot) {
+        char* dst = smem + Geo::A_RING + slot * Geo::W_STAGE + (wave & 1) * 2 * PL * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) glds16(w_src[j] + ((size_t)st * PL + pl) * 1024, dst + (j * PL + pl) * 1024);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    const int my_row = wave * 32 + r;
+    const int sw = (my_row >> 2) & 3;
+    const int a_off0 = my_row * 64 + (((2 * h) ^ sw) << 4), a_off1 = my_row * 64 + (((2 * h + 1) ^ sw) << 4);
+
+    if (loader_a) {
+#pragma unroll
+        for (int st = 0; st < NA - 1; ++st) issue_a(st < n_stages ? st : n_stages - 1, st);
+    } else {
+#pragma unroll
+        for (int st = 0; st < NW - 1; ++st) issue_w(st < n_stages ? st : n_stages - 1, st);
+    }
+    constexpr int kTerm[6][2] = {{0, 2}, {2, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    int sa = 0, sw_ = 0;   // slots of stage st in the two rings
+    for (int st = 0; st < n_stages; ++st) {
+        // this wave's own DMAs of stage st have landed when only the younger stages' are outstanding ...
+        if (loader_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo::GA * (NA - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo::GW * (NW - 2)) : "memory");
+        // ... after the barrier everybody's have, and everybody is done reading stage st - 1: its slots are free
+        __builtin_amdgcn_s_barrier();
+        if (loader_a) {
+            const int nx = st + NA - 1;
+            issue_a(nx < n_stages ? nx : n_stages - 1, sa == 0 ? NA - 1 : sa - 1);
+        } else {
+            const int nx = st + NW - 1;
+            issue_w(nx < n_stages ? nx : n_stages - 1, sw_ == 0 ? NW - 1 : sw_ - 1);
+        }
+        const char* aslot = smem + sa * Geo::A_STAGE;
+        const char* wbase = smem + Geo::A_RING + sw_ * Geo::W_STAGE + lane * 16;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(aslot + a_off0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(aslot + a_off1);
+        if constexpr (MODE == 0) {
+            bf16x8 af[3];
+            wl_split3(x0, x1, af);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                bf16x8 wf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[pl] = *reinterpret_cast<const bf16x8*>(wbase + (b * PL + pl) * 1024);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc[b] = RAGB_WL_MFMA_BF16(wf[kTerm[t][0]], af[kTerm[t][1]], acc[b]);
+            }
+        } else {
+            f16x8 af;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[e] = (_Float16)(e < 4 ? x0[e] : x1[e - 4]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f16x8 wf = *reinterpret_cast<const f16x8*>(wbase + b * PL * 1024);
+                acc[b] = RAGB_WL_MFMA_F16(wf, af, acc[b]);
+            }
+        }
+        sa = sa + 1 == NA ? 0 : sa + 1;
+        sw_ = sw_ + 1 == NW ? 0 : sw_ + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+}
+
+// ---- software-pipelined form --------------------------------------------------------------------------------------
+// The ablations of the forms above (MFMAs removed: 60 % of the time remains; ring depth and who issues what: no
+// effect) say the time is ISSUE time: a wave runs its stage strictly in order — five DMA issues (~100 cycles each),
+// fourteen LDS reads, ~50 conversion instructions, THEN twenty-four MFMAs — and nothing of its own overlaps the MFMAs.
+// An MFMA holds the SIMD's issue port for 8 of its 32 cycles, so everything else fits in the MFMAs' shadow if it sits
+// BETWEEN them in program order.  For that the other work must not depend on this stage's wait:
+//   * A runs one stage further ahead than W (ring of 4 against 3): a wave issues A(st + 3) before W(st + 2), so the one
+//     counted wait at the top of stage st that retires W(st) has also retired this wave's own A(st + 1) rows;
+//   * the A fragment of stage st + 1 is read and split during stage st's MFMAs (its rows are this wave's own DMAs:
+//     no barrier needed), the DMAs of the coming stages are issued between MFMAs too;
+//   * sched_group_barrier pins the interleave (left alone hipcc clusters the MFMAs at the end).
+template <int MODE>
+struct Wl4Geom {
+    static constexpr int PL = MODE == 0 ? 3 : 1;
+    static constexpr int NA = 4, NW = 3;
+    static constexpr int A_STAGE = 128 * 64;
+    static constexpr int W_STAGE = 4 * PL * 1024;
+    static constexpr int A_RING = NA * A_STAGE;
+    static constexpr int RING = A_RING + NW * W_STAGE;
+    static constexpr int EPI = 4 * 16 * 132 * 4;
+    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static constexpr int G = 2 + PL;                          // LDS-DMA instructions per wave per stage
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_wl4_kernel(const GemmWlParams p) {
+    using Geo = Wl4Geom<MODE>;
+    constexpr int PL = Geo::PL, NA = Geo::NA, NW = Geo::NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int m0, n0;
+    if (!xcd_tile(p.M, p.N, 128, 128, m0, n0)) return;
+    const int n_stages = p.K / 16;
+
+    const char* a_src[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;
+        a_src[q] = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16;
+    }
+    int nt_w = (n0 >> 5) + wave;
+    nt_w = nt_w < (p.N >> 5) ? nt_w : (p.N >> 5) - 1;
+    const char* w_src = static_cast<const char*>(p.Wimg) + (size_t)nt_w * n_stages * PL * 1024 + lane * 16;
+    auto issue_a = [&](int st) {   // this wave's 32 rows of stage st (clamped) into A slot st % NA
+        const int sc = st < n_stages ? st : n_stages - 1;
+        char* dst = smem + (st % NA) * Geo::A_STAGE + wave * 32 * 64;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) glds16(a_src[q] + (size_t)sc * 64, dst + q * 1024);
+    };
+    auto issue_w = [&](int st) {   // column tile `wave` of stage st (clamped) into W slot st % NW
+        const int sc = st < n_stages ? st : n_stages - 1;
+        char* dst = smem + Geo::A_RING + (st % NW) * Geo::W_STAGE + wave * PL * 1024;
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) glds16(w_src + ((size_t)sc * PL + pl) * 1024, dst + pl * 1024);
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    const int my_row = wave * 32 + r;
+    const int sw = (my_row >> 2) & 3;
+    const int a_off0 = my_row * 64 + (((2 * h) ^ sw) << 4), a_off1 = my_row * 64 + (((2 * h + 1) ^ sw) << 4);
+
+    // prologue, in the steady-state order A(s + 1) before W(s):  A0 | A1 W0 | A2 W1
+    issue_a(0);
+    issue_a(1); issue_w(0);
+    issue_a(2); issue_w(1);
+    bf16x8 af[3];
+    f16x8 ah;
+    auto take_a = [&](int st) {   // A fragment of stage st (this wave's own rows, landed) -> af / ah
+        const char* slot = smem + (st % NA) * Geo::A_STAGE;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(slot + a_off0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(slot + a_off1);
+        if constexpr (MODE == 0) {
+            wl_split3(x0, x1, af);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ah[e] = (_Float16)(e < 4 ? x0[e] : x1[e - 4]);
+        }
+    };
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Geo::G) : "memory");   // A0 has landed (behind it: A1 W0 A2 W1)
+    take_a(0);
+    constexpr int kTerm[6][2] = {{0, 2}, {2, 0}, {1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    for (int st = 0; st < n_stages; ++st) {
+        // outstanding here: A(st+1) W(st) | A(st+2) W(st+1).  All but the youngest G: W(st) has landed — and so has
+        // this wave's A(st+1), issued just before it
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo::G) : "memory");
+        __builtin_amdgcn_s_barrier();   // everybody's W(st) is in; everybody is done with W(st-1): its slot is free
+        const char* wbase = smem + Geo::A_RING + (st % NW) * Geo::W_STAGE + lane * 16;
+        if constexpr (MODE == 0) {
+            bf16x8 wf[4][3];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[b][pl] = *reinterpret_cast<const bf16x8*>(wbase + (b * PL + pl) * 1024);
+            const bf16x8 ac[3] = {af[0], af[1], af[2]};
+            // A(st+1), this wave's own rows, for the split below
+            const char* nslot = smem + ((st + 1) % NA) * Geo::A_STAGE;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(nslot + a_off0);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(nslot + a_off1);
+            // the coming stages' DMAs: destination and source of each of this wave's five instructions
+            const int sa3 = st + 3 < n_stages ? st + 3 : n_stages - 1, sw2 = st + 2 < n_stages ? st + 2 : n_stages - 1;
+            char* a_dst = smem + ((st + 3) % NA) * Geo::A_STAGE + wave * 32 * 64;
+            char* w_dst = smem + Geo::A_RING + ((st + 2) % NW) * Geo::W_STAGE + wave * PL * 1024;
+            __builtin_amdgcn_sched_barrier(0);
+            // 24 MFMAs, one at a time, each followed by a slice of the other work — pinned: an MFMA occupies the
+            // SIMD's issue port for 8 of its 32 cycles, what sits right behind it runs in its shadow
+            float r1[8];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int t = i >> 2, b = i & 3;
+                acc[b] = RAGB_WL_MFMA_BF16(wf[b][kTerm[t][0]], ac[kTerm[t][1]], acc[b]);
+                if (i == 1) glds16(a_src[0] + (size_t)sa3 * 64, a_dst);
+                if (i == 3) glds16(a_src[1] + (size_t)sa3 * 64, a_dst + 1024);
+                if (i == 5) glds16(w_src + ((size_t)sw2 * PL + 0) * 1024, w_dst);
+                if (i == 7) glds16(w_src + ((size_t)sw2 * PL + 1) * 1024, w_dst + 1024);
+                if (i == 9) glds16(w_src + ((size_t)sw2 * PL + 2) * 1024, w_dst + 2048);
+                if (i >= 8) {   // elements 2 (i - 8) / 4 ... : two elements per pair of MFMAs, in two half-steps
+                    const int e0 = ((i - 8) >> 1) * 1;   // element handled by this pair of slots: 0..7
+                    const float x = e0 < 4 ? x0[e0] : x1[e0 - 4];
+                    if (((i - 8) & 1) == 0) {
+#if defined(RAGB_WL_NO_SPLIT)
+                        af[0][e0] = __builtin_bit_cast(__bf16, (unsigned short)(__float_as_uint(x) >> 16));
+                        r1[e0] = 0.f;
+#else
+                        const __bf16 hi = (__bf16)x;
+                        af[0][e0] = hi;
+                        r1[e0] = x - (float)hi;
+#endif
+                    } else {
+#if defined(RAGB_WL_NO_SPLIT)
+                        af[1][e0] = af[0][e0];
+                        af[2][e0] = af[0][e0];
+#else
+                        const __bf16 mid = (__bf16)r1[e0];
+                        af[1][e0] = mid;
+                        af[2][e0] = (__bf16)(r1[e0] - (float)mid);
+#endif
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            f16x8 wf[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) wf[b] = *reinterpret_cast<const f16x8*>(wbase + b * PL * 1024);
+            const f16x8 ac = ah;
+            issue_a(st + 3);
+            issue_w(st + 2);
+            take_a(st + 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = RAGB_WL_MFMA_F16(wf[b], ac, acc[b]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+}
+
+}  // namespace ragb

@@ -18,8 +18,7 @@ namespace {
 constexpr int kPerLayer = 12;
 constexpr int kEmbEntries = 5;
 
-int f16_base(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
-int weight_count(const rag_bert_config& c) { return f16_base(c) + (c.gemm_mode == RAG_GEMM_F16 ? 4 * c.n_layers : 0); }
+int weight_count(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
 
 int map_act(int act) {
     switch (act) {
@@ -38,8 +37,18 @@ struct rag_bert {
     int n_cus = 256;
     bool valu_attention = false;  // RAG_AMD_VALU_ATTENTION=1: the VALU attention kernel (A/B checks)
     std::vector<const float*> w;
-    // RAG_GEMM_F32: split-bf16 images of the four GEMM weights of every layer (pack_x6_kernel), owned here
+    // Fragment-order images of the four GEMM weights of every layer, owned here (gemm_wl.hip.h):
+    //   wx2  RAG_GEMM_F32: two fp16 planes (hi, scaled lo) — the default big-batch path
+    //   wx   RAG_GEMM_F32: three bf16 planes — built only when a value outside fp16's range has been seen
+    //   wxf  RAG_GEMM_F16: one fp16 plane
+    std::vector<_Float16*> wx2;
     std::vector<__bf16*> wx;
+    std::vector<_Float16*> wxf;
+    uint32_t* range_flag = nullptr;   // device word: a big-batch GEMM met |a| >= 65504 (or a weight did, at creation)
+    uint32_t* range_pin = nullptr;    // pinned host copy, read back with the results
+    bool weights_fit_f16 = true;      // every GEMM weight is inside fp16's range: the two-plane images are valid
+    bool force_x6 = false;            // this forward pass runs its big-batch GEMMs on the split-bf16 images
+    long long range_events = 0;       // forward passes repeated on the split-bf16 path
     hipStream_t stream = nullptr;
     std::mutex mu;
     // activation workspace, sized for ws_tokens tokens / ws_seqs sequences
@@ -116,9 +125,36 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
 // a split-bf16 image (RAG_GEMM_F32, built at create).
 struct WRef {
     const float* w;
-    const _Float16* w16;
-    const __bf16* wx;
+    const _Float16* wx2;   // two fp16 planes, fragment order (null: not available / not valid)
+    const __bf16* wx;      // three bf16 planes, fragment order (null: not built)
+    const _Float16* wxf;   // one fp16 plane, fragment order (RAG_GEMM_F16)
+    uint32_t* range_flag;  // the model's "outside fp16's range" word
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel (sizes above 64 KiB need it)
+int ensure_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, const void*>, int>> granted;
+    int dev = 0;
+    RAGC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& g : granted)
+        if (g.first.first == dev && g.first.second == fn && g.second >= bytes) return RAG_OK;
+    RAGC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    granted.push_back({{dev, fn}, bytes});
+    return RAG_OK;
+}
+
+template <int MODE, int KS, int NS, bool PIPE>
+int launch_wl(const ragb::GemmWlParams& g, hipStream_t st) {
+    using Geo = ragb::WlGeom<MODE, KS, NS>;
+    auto fn = &ragb::gemm_nt_wl_kernel<MODE, KS, NS, PIPE>;
+    int rc = ensure_lds(reinterpret_cast<const void*>(fn), Geo::LDS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(ragb::xcd_grid(g.M, g.N, 128, 128)), dim3(256), Geo::LDS, st, g);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
 
 // Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip; big M
 // runs on the bf16 matrix cores with fp32 accuracy (split-bf16 image), or takes fp16 inputs when the
@@ -126,21 +162,19 @@ struct WRef {
 int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* bias, const float* R,
                 int ldr, float* C, int ldc, int M, int N, int K, int act, hipStream_t st, int n_cus = 256) {
     const float* W = Wr.w;
-    const _Float16* W16 = Wr.w16;
     if (M <= 0) return RAG_OK;
-    if (M > 1024 && Wr.wx && K % ragb::XBK == 0 && ldw == K) {
-        ragb::GemmX6Params g{A, Wr.wx, bias, R, C, M, N, K, lda, ldr, ldc, act};
-        dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);
-        ragb::gemm_nt_x6_kernel<<<grid, dim3(256), 0, st>>>(g);
-        RAGC_HIP_TRY(hipGetLastError());
-        return RAG_OK;
+    // big batches: both operands through LDS-DMA (gemm_wl.hip.h); the variants per shape are the faster ones of
+    // scripts/exp/gemm_wl_bench.hip on the cross-encoder's shapes
+    const bool wl_ok = M > 1024 && ldw == K && N % 32 == 0 && (lda % 4) == 0;
+    if (wl_ok && Wr.wx2 && K % 16 == 0)   // fp32 results: two fp16 planes per operand, three products
+        return launch_wl<2, 1, 3, false>(ragb::GemmWlParams{A, Wr.wx2, bias, R, C, M, N, K, lda, ldr, ldc, act, Wr.range_flag}, st);
+    if (wl_ok && Wr.wx && K % 16 == 0) {  // fp32 results, fp32 range: three bf16 planes, six products
+        const ragb::GemmWlParams g{A, Wr.wx, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
+        return N <= 512 ? launch_wl<0, 1, 3, true>(g, st) : launch_wl<0, 1, 3, false>(g, st);
     }
-    if (M > 1024 && W16 && K % ragb::HBK == 0) {
-        ragb::GemmF16Params g{A, W16, bias, R, C, M, N, K, lda, ldw, ldr, ldc, act};
-        dim3 grid(ragb::xcd_grid(M, N, 128, 128), 1, 1);
-        ragb::gemm_nt_f16_kernel<<<grid, dim3(256), 0, st>>>(g);
-        RAGC_HIP_TRY(hipGetLastError());
-        return RAG_OK;
+    if (wl_ok && Wr.wxf && K % 32 == 0) {  // fp16 inputs (the reference's GPU reranker precision)
+        const ragb::GemmWlParams g{A, Wr.wxf, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
+        return K <= 512 ? launch_wl<1, 1, 4, true>(g, st) : launch_wl<1, 2, 3, false>(g, st);
     }
     ragb::GemmParams g;
     g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
@@ -286,11 +320,12 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     bool compact = false;  // h->pooled holds the final hidden state of the first tokens, one row per sequence
     for (int l = 0; l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
-        const _Float16* const* lh =
-            c.gemm_mode == RAG_GEMM_F16 ? reinterpret_cast<const _Float16* const*>(w + f16_base(c) + 4 * l) : nullptr;
         const int wsrc[4] = {0, 2, 6, 8};  // qkv_w, attn_out_w, ffn_in_w, ffn_out_w in the layer's table
         auto wref = [&](int i) -> WRef {
-            return WRef{lw[wsrc[i]], lh ? lh[i] : nullptr, h->wx.empty() ? nullptr : h->wx[(size_t)4 * l + i]};
+            const size_t at = (size_t)4 * l + i;
+            const bool two_plane = !h->force_x6 && h->weights_fit_f16 && !h->wx2.empty();
+            return WRef{lw[wsrc[i]], two_plane ? h->wx2[at] : nullptr, h->wx.empty() ? nullptr : h->wx[at],
+                        h->wxf.empty() ? nullptr : h->wxf[at], h->range_flag};
         };
         // QKV projection
         rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st, h->n_cus);
@@ -358,7 +393,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
                 RAGC_HIP_TRY(hipGetLastError());
             }
-            rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
+            rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr, nullptr, nullptr}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
             if (rc) return rc;
             const bool probs = out_kind == RAG_BERT_OUT_PROBS;
             head_out_kernel<<<dim3(nseq, c.n_labels), dim3(64), 0, st>>>(h->pooled2, hw[2], hw[3], probs ? h->logits : out,
@@ -381,6 +416,47 @@ int check_forward(const rag_bert* h, int nseq, int out_kind) {
     return RAG_OK;
 }
 
+}  // namespace
+
+namespace {
+// Build the fragment-order images of every layer's four GEMM weights: kind 0 three bf16 planes (wx), 1 one fp16
+// plane (wxf), 2 two fp16 planes (wx2; weights outside fp16's range raise h->range_flag).  Synchronises h->stream.
+int build_images(rag_bert* h, int kind) {
+    const rag_bert_config& c = h->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    const int shape[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};
+    const int wsrc[4] = {0, 2, 6, 8};
+    const size_t n_img = (size_t)4 * c.n_layers;
+    if (kind == 0 && !h->wx.empty()) return RAG_OK;
+    if (kind == 0) h->wx.assign(n_img, nullptr);
+    if (kind == 1) h->wxf.assign(n_img, nullptr);
+    if (kind == 2) h->wx2.assign(n_img, nullptr);
+    const size_t bytes_per_elem = kind == 0 ? 6 : (kind == 1 ? 2 : 4);
+    for (int l = 0; l < c.n_layers; ++l) {
+        for (int i = 0; i < 4; ++i) {
+            const int N = shape[i][0], K = shape[i][1];
+            void* img = nullptr;
+            if (hipMalloc(&img, (size_t)N * K * bytes_per_elem) != hipSuccess)
+                return ragc_fail(RAG_ERR_OOM, "device allocation of the fragment-order weight images failed");
+            const size_t at = (size_t)4 * l + i;
+            const float* W = h->w[kEmbEntries + kPerLayer * l + wsrc[i]];
+            const dim3 grid((unsigned)(((long long)N * K + 255) / 256));
+            if (kind == 0) {
+                h->wx[at] = static_cast<__bf16*>(img);
+                ragb::pack_x6_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wx[at]);
+            } else if (kind == 1) {
+                h->wxf[at] = static_cast<_Float16*>(img);
+                ragb::pack_f16_frag_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wxf[at]);
+            } else {
+                h->wx2[at] = static_cast<_Float16*>(img);
+                ragb::pack_f16x2_frag_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wx2[at], h->range_flag);
+            }
+        }
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+        return ragc_fail(RAG_ERR_HIP, "building the fragment-order weight images failed");
+    return RAG_OK;
+}
 }  // namespace
 
 extern "C" int32_t rag_bert_weight_count(const rag_bert_config* cfg) { return cfg ? weight_count(*cfg) : 0; }
@@ -430,30 +506,36 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
     const char* va = getenv("RAG_AMD_VALU_ATTENTION");
     h->valu_attention = va && *va == '1';
+    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(h->range_flag, 0, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        rag_bert_destroy(h);
+        return ragc_fail(RAG_ERR_OOM, "allocation of the range flag failed");
+    }
+    *h->range_pin = 0;
+    // fragment-order images of the layer GEMM weights (read once, here: later in-place edits of the caller's
+    // tensors are not seen by the big-batch path)
+    int rc = RAG_OK;
+    if (c.gemm_mode == RAG_GEMM_F32) rc = build_images(h, 2);
+    else if (c.gemm_mode == RAG_GEMM_F16) rc = build_images(h, 1);
+    if (rc) {
+        rag_bert_destroy(h);
+        return rc;
+    }
     if (c.gemm_mode == RAG_GEMM_F32) {
-        // split-bf16 images of the layer GEMM weights (read once, here: later in-place edits of the
-        // caller's tensors are not seen by the big-batch path)
-        const int H = c.hidden, I = c.intermediate;
-        const int shape[4][2] = {{3 * H, H}, {H, H}, {I, H}, {H, I}};
-        const int wsrc[4] = {0, 2, 6, 8};
-        h->wx.assign((size_t)4 * c.n_layers, nullptr);
-        for (int l = 0; l < c.n_layers; ++l) {
-            for (int i = 0; i < 4; ++i) {
-                const int N = shape[i][0], K = shape[i][1];
-                __bf16* img = nullptr;
-                if (hipMalloc(reinterpret_cast<void**>(&img), (size_t)N * K * 3 * sizeof(__bf16)) != hipSuccess) {
-                    rag_bert_destroy(h);
-                    return ragc_fail(RAG_ERR_OOM, "device allocation of the split-bf16 weight images failed");
-                }
-                h->wx[(size_t)4 * l + i] = img;
-                const long long total = (long long)N * K;
-                ragb::pack_x6_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream>>>(
-                    h->w[kEmbEntries + kPerLayer * l + wsrc[i]], N, K, K, img);
-            }
-        }
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        // a weight outside fp16's range (never seen in a BERT-family checkpoint) invalidates the two-plane images
+        uint32_t flag = 0;
+        if (hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) {
             rag_bert_destroy(h);
-            return ragc_fail(RAG_ERR_HIP, "building the split-bf16 weight images failed");
+            return ragc_fail(RAG_ERR_HIP, "reading the range flag failed");
+        }
+        if (flag) {
+            h->weights_fit_f16 = false;
+            (void)hipMemset(h->range_flag, 0, sizeof(uint32_t));
+            if ((rc = build_images(h, 0))) {
+                rag_bert_destroy(h);
+                return rc;
+            }
         }
     }
     *out = h;
@@ -472,6 +554,12 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
             if (p) (void)hipFree(p);
         for (__bf16* p : h->wx)
             if (p) (void)hipFree(p);
+        for (_Float16* p : h->wx2)
+            if (p) (void)hipFree(p);
+        for (_Float16* p : h->wxf)
+            if (p) (void)hipFree(p);
+        if (h->range_flag) (void)hipFree(h->range_flag);
+        if (h->range_pin) (void)hipHostFree(h->range_pin);
         if (h->stage_pin) (void)hipHostFree(h->stage_pin);
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);
         if (h->stage_event) (void)hipEventDestroy(h->stage_event);
@@ -593,6 +681,37 @@ extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* 
                         h->out_dev, st);
     if (rc) return rc;
     RAGC_HIP_TRY(hipMemcpyAsync(out, h->out_dev, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->range_pin, h->range_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RAGC_HIP_TRY(hipStreamSynchronize(st));
+    if (*h->range_pin) {
+        // An activation outside fp16's range (|x| >= 65504) went through the two-plane GEMMs: that pass is void.
+        // Repeat it on the split-bf16 images (fp32's exponent range), built now if this is the first time.
+        *h->range_pin = 0;
+        RAGC_HIP_TRY(hipMemsetAsync(h->range_flag, 0, sizeof(uint32_t), st));
+        if ((rc = build_images(h, 0))) return rc;
+        h->force_x6 = true;
+        rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind,
+                            normalize, h->out_dev, st);
+        h->force_x6 = false;
+        if (rc) return rc;
+        ++h->range_events;
+        RAGC_HIP_TRY(hipMemcpyAsync(out, h->out_dev, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+        RAGC_HIP_TRY(hipStreamSynchronize(st));
+    }
+    return RAG_OK;
+}
+
+extern "C" int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pending) {
+    if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
+    RagcDeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (repeated_passes) *repeated_passes = h->range_events;
+    if (pending) {   // a pass of one of the asynchronous entry points raised the flag since it was last taken
+        uint32_t flag = 0;
+        RAGC_HIP_TRY(hipDeviceSynchronize());
+        RAGC_HIP_TRY(hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) RAGC_HIP_TRY(hipMemset(h->range_flag, 0, sizeof flag));
+        *pending = flag ? 1 : 0;
+    }
     return RAG_OK;
 }

@@ -18,13 +18,13 @@ BIG_M = 1024                 # tokens above which the GEMMs take the big-batch k
 
 def mode_peak(gemm_dtype, tokens):
     """(peak TF/s in fp32-equivalent GEMM flops, what bounds it) of the GEMM path a stage actually runs on:
-    small batches stay on the fp32 MFMA whatever the mode; big batches run six bf16 MFMAs per product in the
-    default mode (2.5 PF / 6), one fp16 MFMA in f16 mode, the fp32 MFMA in strict mode."""
+    small batches stay on the fp32 MFMA whatever the mode; big batches run three fp16 MFMAs per product in the
+    default mode (two-plane split, 2.5 PF / 3), one fp16 MFMA in f16 mode, the fp32 MFMA in strict mode."""
     if tokens <= BIG_M or gemm_dtype == "f32_strict":
         return FP32_MFMA_PEAK_TF, "fp32 MFMA (157.3 TF/s)"
     if gemm_dtype == "f16":
         return BF16_MFMA_PEAK_TF, "fp16 MFMA (2.5 PF/s dense)"
-    return BF16_MFMA_PEAK_TF / 6.0, "bf16 MFMA, six products per fp32 product (2.5 PF/s / 6 = 417 TF/s fp32-equivalent)"
+    return BF16_MFMA_PEAK_TF / 3.0, "fp16 MFMA, three products per fp32 product (2.5 PF/s / 3 = 833 TF/s fp32-equivalent)"
 
 
 def gemm_flops(cfg, T, nseq, head, first_only=False):
@@ -89,7 +89,7 @@ def run(name, cfg, lens, out_kind, reps=10, cpu_sample=0, threads=16, gemm_dtype
            "attention_gflop": attn_flops(cfg, lens) / 1e9, "gemm_tflops_end_to_end": gf / ms / 1e9,
            "mfma_peak_tflops_of_this_mode": mode_peak(gemm_dtype, T)[0], "mfma_peak_basis": mode_peak(gemm_dtype, T)[1],
            "frac_of_mode_mfma_peak": gf / ms / 1e9 / mode_peak(gemm_dtype, T)[0], "sequences_per_s": nseq / ms * 1e3,
-           "dtype": {"f32": "f32 (big-batch GEMMs: exact 3-way bf16 split, 6 products, on the bf16 matrix cores)",
+           "dtype": {"f32": "f32 (big-batch GEMMs: two fp16 planes per operand, 3 products, on the fp16 matrix cores)",
                      "f32_strict": "f32 on the fp32 MFMA throughout",
                      "f16": "f16 GEMM inputs, f32 accumulate / softmax / LayerNorm"}[gemm_dtype]}
     print(f"{name}: nseq={nseq} tokens={T} maxlen={L}: {ms:.3f} ms/batch  GEMM {gf/1e9:.1f} GFLOP -> {gf/ms/1e9:.1f} TF/s "

@@ -182,3 +182,50 @@ def test_split_bf16_gemms_keep_fp32_accuracy(gpu_required):
     assert e_strict < 2e-5 and e_split < 2e-5, (e_split, e_strict)
     assert e_split < 3 * e_strict + 1e-6, (e_split, e_strict)            # same accuracy class as the fp32 MFMA
     assert np.abs(got_split - got_strict).max() > 0                      # and it really is another arithmetic
+
+
+def test_values_outside_fp16_range_take_the_three_plane_path(gpu_required):
+    """Default big-batch GEMMs write every fp32 operand as two fp16 numbers (include/rag_amd.h RAG_GEMM_F32): a value
+    beyond fp16's range cannot go that way.  An activation of 1e5 (a feed-forward bias pushed there) raises the range
+    flag and the pass is repeated on the three-plane bf16 split; a WEIGHT of 1e5 keeps the model on that path from the
+    start.  Either way the result is the fp32-MFMA path's, to fp32 rounding."""
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    rng = np.random.default_rng(21)
+    seqs = _seqs(rng, rng.integers(24, 65, size=40), cfg.vocab_size)     # ~1800 tokens: the big-batch path
+    types = [[0] * 8 + [1] * (len(s) - 8) for s in seqs]
+
+    def run(w, dtype):
+        c = _small(BertConfig.ms_marco_minilm_l6())
+        c.gemm_dtype = dtype
+        m = BertModel(c, w)
+        out = m.hidden_states(seqs, types)
+        ev = m.range_events()[0]
+        out2 = m.hidden_states(seqs, types)      # a second pass: the images built on first need are reused
+        ev2 = m.range_events()[0]
+        m.close()
+        np.testing.assert_array_equal(out, out2)
+        return out, ev, ev2
+
+    w = random_weights(cfg, 21)
+    base, ev, _ = run(w, "f32")
+    assert ev == 0                                                   # ordinary values: nothing repeated
+    w_act = dict(w)
+    b = w["layer1.ffn_in_b"].copy()
+    b[:7] = 1.0e5                                                    # GELU(1e5) = 1e5 feeds the ffn_out GEMM
+    w_act["layer1.ffn_in_b"] = b
+    got, ev, ev2 = run(w_act, "f32")
+    want, _, _ = run(w_act, "f32_strict")
+    assert ev == 1 and ev2 == 2                                      # every such pass is repeated, none is wrong
+    assert np.isfinite(got).all()
+    # (sums of terms of magnitude 1e4 in front of a LayerNorm: the two paths' fp32 summation orders differ by more
+    # than they do on ordinary values)
+    np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-5)
+    w_big = dict(w)
+    ww = w["layer2.attn_out_w"].copy()
+    ww[3, 5] = 1.0e5
+    w_big["layer2.attn_out_w"] = ww
+    got, ev, _ = run(w_big, "f32")
+    want, _, _ = run(w_big, "f32_strict")
+    assert ev == 0                                                   # known at creation: no pass is ever repeated
+    np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-5)
+    assert np.abs(base - got).max() > 0
