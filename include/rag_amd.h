@@ -256,7 +256,7 @@ typedef struct rag_bert_config {
     int32_t gemm_mode;     /* RAG_GEMM_*: how big-batch (> 1024 tokens) GEMMs run */
 } rag_bert_config;
 
-/* RAG_GEMM_F32 (default): fp32 results.  Big-batch GEMMs run on the fp16 matrix cores with every fp32 operand
+/* RAG_GEMM_F32 (default): fp32 results.  The layers' GEMMs run on the fp16 matrix cores with every fp32 operand
  *   written as TWO fp16 numbers — hi = fp16(x), lo = fp16((x - hi) 2^11): 22 significand bits — and the three products
  *   hi hi, lo hi, hi lo accumulated in fp32 (the cross terms in their own accumulator, scaled by 2^-11 at the end): the
  *   error stays below the fp32 accumulation's own rounding (measured against float64: at or below the fp32-MFMA
@@ -296,11 +296,22 @@ int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* type_ids, c
                      int32_t nseq, int32_t out_kind, int32_t normalize, float* out);
 
 /* Same with ids / type_ids / cu_seqlens / out in device memory (total_tokens = cu_seqlens[nseq],
- * max_seq_len = longest sequence); asynchronous on `stream`. */
+ * max_seq_len = longest sequence); asynchronous on `stream`.  range_flag (RAG_GEMM_F32; NULL = the handle's own word,
+ * see rag_bert_range_events): a 32-bit word in PINNED HOST memory the device can write (hipHostMalloc / torch
+ * pin_memory), zeroed by the caller — the GEMM kernels store 1 into it when an activation of this pass is outside
+ * fp16's range (|x| >= 65504), in which case the pass's output is void and the caller repeats it through the
+ * host-pointer entry point (which falls back to fp32's range by itself).  Read it once `stream` has passed the pass. */
 int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* type_ids_dev,
                             const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
                             int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
-                            void* stream);
+                            uint32_t* range_flag, void* stream);
+
+/* Background mode (off by default): small-batch GEMMs (<= 1024 tokens: the query encoder) run in a form that needs
+ * 32 KiB of LDS and four waves per workgroup instead of 96-144 KiB and sixteen.  For a caller that runs the encoder on
+ * a side stream UNDER a long-running kernel of another stream — the corpus scan keeps a workgroup with 65-115 KiB of
+ * LDS resident on every CU for milliseconds, and only workgroups that fit beside it start before it ends.  Slower
+ * when nothing else runs (a barrier per 16-deep K-step), same results.  (No counterpart in the reference.) */
+int rag_bert_set_background(rag_bert* h, int32_t on);
 
 /* Passes the host-pointer entry point has repeated on the three-plane path because an activation left fp16's range
  * (RAG_GEMM_F32, see above).  `pending` (may be NULL; synchronises the device when given): 1 when a pass of one of the
@@ -314,10 +325,10 @@ int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pendin
  * pass is enqueued behind them, and the call returns WITHOUT waiting: *stream_out is that stream (a hipStream_t),
  * on which the consumer enqueues its own work (rag_index_search_device_host_out) or which it synchronises.
  * out_dev is caller-owned device memory (nseq x hidden / n_labels floats, by out_kind) and must stay allocated
- * until that stream has passed this call's work. */
+ * until that stream has passed this call's work.  range_flag: as for rag_bert_forward_device. */
 int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const int32_t* type_ids,
                                const int32_t* cu_seqlens, int32_t nseq, int32_t out_kind, int32_t normalize,
-                               float* out_dev, void** stream_out);
+                               float* out_dev, uint32_t* range_flag, void** stream_out);
 
 /* ---- `compressed` document payload (host side) ------------------------------------------- */
 
@@ -331,6 +342,20 @@ int64_t rag_lz4_block_compress(const uint8_t* src, int64_t n, uint8_t* dst, int6
 
 /* xxHash32 (the LZ4 frame header checksum byte is (xxh32(descriptor, 0) >> 8) & 0xFF). */
 uint32_t rag_xxh32(const uint8_t* data, int64_t n, uint32_t seed);
+
+/* ---- stand-in tokenizer of the synthetic models (host side) --------------------------------------- */
+
+/* (query, document) pairs -> the packed arrays rag_bert_forward takes, for ASCII text and the stand-in vocabulary of
+ * models without a checkpoint (model_source.HashTokenizer: lower-cased word / punctuation pieces, id = first_id +
+ * crc32(piece) % span): [cls] a [sep] b [sep] with token types 0 / 1, or <s> a </s></s> b </s> when roberta != 0,
+ * truncated longest-first to max_length — what the reference asks of its tokenizer (reranker.py:237-246).
+ * ids_out / types_out (may be NULL) hold `cap` entries, cu_out n_pairs + 1.  Returns the total number of tokens;
+ * -1 if a text holds a non-ASCII byte (the caller falls back to its own regex), -2 if cap is too small, -3 on bad
+ * arguments. */
+int64_t rag_hash_encode_pairs(const uint8_t* const* first, const int64_t* first_len, const uint8_t* const* second,
+                              const int64_t* second_len, int64_t n_pairs, int32_t max_length, int32_t roberta,
+                              int32_t first_id, int32_t span, int32_t cls_id, int32_t sep_id, int32_t* ids_out,
+                              int32_t* types_out, int32_t* cu_out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -17,9 +17,9 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
-_SOURCES = ["rag_amd.hip", "rag_bert.hip", "rag_lz4.cpp"]
+_SOURCES = ["rag_amd.hip", "rag_bert.hip", "rag_lz4.cpp", "rag_text.cpp"]
 _DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "gemm_wl.hip.h", "rag_common.h",
-         "rag_lz4.cpp"]
+         "rag_lz4.cpp", "rag_text.cpp"]
 
 RAG_OK = 0
 RAG_ERR_INVALID_ARG = 1
@@ -123,6 +123,8 @@ def _declare(lib: C.CDLL) -> None:
         "rag_lz4_compress_bound": (C.c_int64, [C.c_int64]),
         "rag_lz4_block_compress": (C.c_int64, [vp, C.c_int64, vp, C.c_int64]),
         "rag_xxh32": (C.c_uint32, [vp, C.c_int64, C.c_uint32]),
+        "rag_hash_encode_pairs": (C.c_int64, [vp, i64p, vp, i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_int32, i32p, i32p, i32p, C.c_int64]),
         "rag_index_set_screening": (C.c_int, [vp, C.c_int32]),
         "rag_index_screening": (C.c_int32, [vp]),
         "rag_index_screen_stats": (C.c_int, [vp, i64p, i64p, C.POINTER(C.c_double), C.c_int32]),
@@ -138,10 +140,11 @@ def _declare(lib: C.CDLL) -> None:
         "rag_bert_destroy": (C.c_int, [vp]),
         "rag_bert_forward": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, f32p]),
         "rag_bert_range_events": (C.c_int, [vp, i64p, i32p]),
-        "rag_bert_forward_to_device": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, vp,
+        "rag_bert_set_background": (C.c_int, [vp, C.c_int32]),
+        "rag_bert_forward_to_device": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, vp, vp,
                                                  C.POINTER(vp)]),
         "rag_bert_forward_device": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                              C.c_int32, vp, vp]),
+                                              C.c_int32, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -295,15 +295,36 @@ class BertModel:
         return out
 
     def forward_device(self, ids_ptr: int, types_ptr: int, cu_ptr: int, nseq: int, total_tokens: int,
-                       max_seq_len: int, out_kind: int, normalize: bool, out_ptr: int, stream: int = 0) -> None:
+                       max_seq_len: int, out_kind: int, normalize: bool, out_ptr: int, stream: int = 0,
+                       range_flag_ptr: int = 0) -> None:
         """Asynchronous forward on device buffers (int32 ids / types / cu_seqlens, fp32 out); pointers as
-        ints, `stream` a hipStream_t.  types_ptr may be 0."""
+        ints, `stream` a hipStream_t.  types_ptr may be 0.  range_flag_ptr: a zeroed pinned-host word that reads 1
+        afterwards if an activation left fp16's range (the pass is then void; 0 = the handle's own word, see
+        range_events)."""
         if not self._h:
             raise RuntimeError("BertModel is closed")
         _native.check(self._lib.rag_bert_forward_device(
             self._h, C.c_void_p(ids_ptr), C.c_void_p(types_ptr or None), C.c_void_p(cu_ptr), int(nseq),
             int(total_tokens), int(max_seq_len), int(out_kind), 1 if normalize else 0, C.c_void_p(out_ptr),
-            C.c_void_p(stream)))
+            C.c_void_p(range_flag_ptr or None), C.c_void_p(stream)))
+
+    def _flag_word(self):
+        """(pinned int32 view of one word, its address): a fresh zeroed word of a small ring for one asynchronous pass."""
+        import torch
+
+        if getattr(self, "_flag_ring", None) is None:
+            self._flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+            self._flag_next = 0
+        i = self._flag_next
+        self._flag_next = (i + 1) % 256
+        word = self._flag_ring[i:i + 1]
+        word.zero_()
+        return word, self._flag_ring.data_ptr() + 4 * i
+
+    def set_background(self, on: bool = True) -> None:
+        """Small-batch GEMMs in their 32-KiB-LDS form, for running the encoder on a side stream under a long-running
+        kernel such as the corpus scan (rag_bert_set_background)."""
+        _native.check(self._lib.rag_bert_set_background(self._h, 1 if on else 0))
 
     def range_events(self, take_pending: bool = False) -> tuple[int, bool]:
         """(forward passes repeated on the three-plane bf16 path because an activation left fp16's range, whether an
@@ -327,12 +348,14 @@ class BertModel:
         i32p = C.POINTER(C.c_int32)
         out = torch.empty((len(seqs), self.cfg.hidden), dtype=torch.float32, device=torch.device("cuda", self.device))
         stream = C.c_void_p()
+        word, word_ptr = self._flag_word()
         _native.check(self._lib.rag_bert_forward_to_device(
             self._h, ids.ctypes.data_as(i32p), types.ctypes.data_as(i32p) if types is not None else None,
             cu.ctypes.data_as(i32p), len(seqs), kind, 1 if normalize else 0, C.c_void_p(out.data_ptr()),
-            C.byref(stream)))
+            C.c_void_p(word_ptr), C.byref(stream)))
         # (a closed model has waited for the device: nothing of its can still be writing to `out`)
-        return DeviceEmbeddings(out, int(stream.value or 0), self.device, producer_alive=lambda: bool(self._h))
+        return DeviceEmbeddings(out, int(stream.value or 0), self.device, producer_alive=lambda: bool(self._h),
+                                range_word=word)
 
     def embed(self, seqs: Sequence[Sequence[int]], type_seqs: Sequence[Sequence[int]] | None = None,
               normalize: bool = True, pooling: str | None = None) -> np.ndarray:

@@ -90,7 +90,10 @@ class EmbeddingGenerator:
         ids, types = self._tokenizer.encode_batch(list(texts), self._max_len)
         if sum(len(s) for s in ids) > _MAX_TOKENS_PER_PASS:
             return self.encode(texts)
-        return self._model.embed_to_device(ids, types, normalize=True)
+        dev = self._model.embed_to_device(ids, types, normalize=True)
+        texts = list(texts)
+        dev.recompute = lambda: self._encode_uncached(texts)   # the host path: fp32's range whatever the values
+        return dev
 
     def encode(self, texts: list[str]) -> np.ndarray:
         if not self._is_loaded or self._model is None:

@@ -123,8 +123,12 @@ class FAISSStore:
                 if self._sharded is None and embeddings.device == self._index.device:
                     res = self._index.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, embeddings.stream)
                     embeddings.settled()  # the call has waited for the stream
-                    return res
-                embeddings = embeddings.numpy()
+                    if embeddings.valid():
+                        return res
+                    # the encoder's pass left fp16's range (device_embeddings.py): the host path repeats it exactly
+                    embeddings = embeddings.numpy()
+                else:
+                    embeddings = embeddings.numpy()
             # the reference converts unconditionally (faiss_store.py:147); a C-contiguous fp32 array is already
             # what the C ABI reads, so it is passed as it is (search never writes to it)
             if not (isinstance(embeddings, np.ndarray) and embeddings.dtype == np.float32 and embeddings.flags.c_contiguous):

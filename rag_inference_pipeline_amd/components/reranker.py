@@ -25,6 +25,8 @@ import logging
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
+
 from ..bert import iter_token_budget, pack_sequences
 from ..config import PipelineSettings, resolve_gpu_device
 from .schemas import Document, RerankedDocument, fast_constructor
@@ -115,6 +117,15 @@ class Reranker:
             lo = hi
 
         def prepare(lo: int, hi: int):
+            packed_fn = getattr(self.tokenizer, "encode_pairs_packed", None)
+            packed = packed_fn(queries[lo:hi], docs[lo:hi], max_len, with_types) if packed_fn is not None else None
+            if packed is not None:   # one native call: already the arrays the model takes
+                ids, types, cu = packed
+                lens = np.diff(cu)
+                if int(cu[-1]) <= _MAX_TOKENS_PER_PASS:
+                    return [(ids, types, cu)]
+                return [(ids[cu[a]:cu[b]], types[cu[a]:cu[b]] if types is not None else None, cu[a:b + 1] - cu[a])
+                        for a, b in iter_token_budget(lens.tolist(), _MAX_TOKENS_PER_PASS)]
             ids, types = self.tokenizer.encode_pairs(queries[lo:hi], docs[lo:hi], max_len)
             parts = []
             for a, b in iter_token_budget([len(s) for s in ids], _MAX_TOKENS_PER_PASS):

@@ -679,4 +679,180 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wl4_kernel(const GemmWlParams 
     wl_epilogue(p, acc, smem, m0, n0, wave, lane);
 }
 
+// ---- small batches (the query encoder: 32 queries ~ 450 tokens) ------------------------------------------------------
+// The same two-plane fp16 arithmetic on 64-row tiles, so that 450 tokens still spread over the chip: a workgroup is
+// 64 rows x 64 NB columns (NB = 1: up to 252 workgroups for bge-base's QKV projection; NB = 2 when that would exceed the
+// CU count), four waves as 2 (rows) x 2 (columns), each 32 rows x 32 NB columns.  The fp32 MFMA these GEMMs ran on
+// needs 512 matrix cycles per 16-deep K-step of a 32 x 32 tile, the three fp16 products need 96; what is left is a
+// stream of W (read once from HBM: every layer's weights exceed the Infinity Cache over a forward pass) and of A (L2),
+// both by LDS-DMA, four K-steps per stage and barrier.  Split-K over blockIdx.z writes fp32 slabs exactly like
+// gemm_nt_small_kernel (splitk_bias_res_ln_kernel reduces them), an unsplit launch applies bias / activation /
+// residual itself.  K range of a split: a multiple of 64.
+// KS_ = 4: the standalone form (96 / 144 KiB of LDS, sixteen waves).  KS_ = 1: the BACKGROUND form — one K-step per stage,
+// four waves, a ring of four 8-KiB stages (32 KiB) — for a caller that runs the encoder on a side stream under a
+// long-running kernel of another stream: the corpus scan holds one workgroup with 65-115 KiB of LDS on every CU for
+// milliseconds, and only kernels that fit beside it (<= 45 KiB) run before it ends (bench.py, pipelined leg).
+template <int NB, int KS_ = 4>
+struct WsGeom {
+    static constexpr int KS = KS_, NS = KS_ == 1 ? 4 : 3;     // (a fourth 32-KiB stage changes nothing: scripts/prof_encoder.py)
+    static constexpr int KG = KS_;                            // wave groups: group g multiplies K-step g of every stage
+    static constexpr int THREADS = 256 * KG;
+    static constexpr int A_STAGE = KS * 64 * 64;              // KS K-steps x 64 rows x 16 fp32
+    static constexpr int W_STAGE = KS * 2 * NB * 2 * 1024;    // KS K-steps x 2 NB column tiles x 2 planes
+    static constexpr int STAGE = A_STAGE + W_STAGE;
+    static constexpr int RED = (KG - 1) * 4 * NB * 16 * 64 * 4;   // partial tiles of groups 1 .. KG-1, parked for the sum (KG > 1)
+    static constexpr int LDS = NS * STAGE > RED ? NS * STAGE : RED;
+    static constexpr int G = 1 + NB;                          // LDS-DMA instructions per wave per stage
+};
+
+struct GemmWsParams {
+    const float* A;
+    const _Float16* Wimg;   // two fp16 planes, fragment order (pack_f16x2_frag_kernel)
+    const float* bias;
+    const float* R;
+    float* C;               // [M][ldc]; with split-K: [splits][M][ldc] partial slabs
+    int M, N, K;
+    int lda, ldr, ldc;
+    int act;
+    int k_per_split;        // K range of one split, multiple of 64; == K when not split
+    int splits;             // the C slabs written: [splits][M][ldc]
+    uint32_t* range_flag;
+};
+
+__host__ __device__ inline int ws_grid(int M, int N, int NB, int splits) {
+    const int mt = (M + 63) / 64, nct = (N + 64 * NB - 1) / (64 * NB);
+    return (nct * splits * mt + 7) / 8 * 8;
+}
+
+// Sixteen waves per workgroup.  With four (one per SIMD) a stage ran strictly in order — DMA issues, LDS reads, the
+// conversion, three MFMAs per K-step, four K-steps — about 1 us per stage whatever the ring depth or the L2 placement
+// (kernel traces, scripts/prof_encoder.py): issue latency, not bandwidth.  Here wave (g, quadrant) takes K-step g of
+// every stage for its 32 x 32 NB quadrant, so four waves per SIMD overlap each other's latencies and each issues a
+// quarter of the DMAs; the four partial tiles of a quadrant are added through LDS at the end, in group order.
+template <int NB, int KS_ = 4>
+__global__ __launch_bounds__((WsGeom<NB, KS_>::THREADS)) void gemm_nt_ws_kernel(const GemmWsParams p) {
+    using Geo = WsGeom<NB, KS_>;
+    constexpr int KS = Geo::KS, NS = Geo::NS, KG = Geo::KG;
+    static_assert(KS == KG, "one K-step of a stage per wave group");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, quad = wave & 3;      // K-step of the stage; quadrant of the tile
+    const int wm = quad >> 1, wn = quad & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware work order (1-D grid of ws_grid() workgroups; the hardware deals workgroup ids round-robin to the 8 XCDs,
+    // each with its own 4 MiB L2).  A unit of work is (column tile, K split, row tile), numbered with the row tile
+    // fastest, and XCD x takes the x-th eighth of that sequence: the row tiles that share a W slice sit on one XCD
+    // (two at a boundary) and every XCD gets the same number of workgroups to within one — with one workgroup per CU
+    // an XCD that holds 33 runs two rounds.
+    const int mt = (p.M + 63) / 64, nct = (p.N + 64 * NB - 1) / (64 * NB);
+    const int units = nct * p.splits * mt, per = (units + 7) / 8;
+    const int slot = (int)blockIdx.x >> 3, unit = ((int)blockIdx.x & 7) * per + slot;
+    if (slot >= per || unit >= units) return;
+    const int cz = unit / mt, kz = cz % p.splits;
+    const int m0 = (unit % mt) * 64, n0 = (cz / p.splits) * 64 * NB;
+    const int nks = p.K / 16;
+    const int ks_beg = kz * (p.k_per_split / 16);
+    const int ks_end = min(nks, ks_beg + p.k_per_split / 16);
+    const int n_stages = (ks_end - ks_beg) / KS;
+    const bool split = p.splits > 1;
+
+    // LDS-DMA sources.  Wave (g, q) brings, of K-step g of every stage: A rows 16 q .. 16 q + 15 (lane l -> row + l / 4,
+    // slot l % 4, source chunk slot ^ ((row >> 2) & 3)), and W fragments q (and q + 4 when NB = 2) of the K-step's
+    // 4 NB (column tile, plane) pairs.
+    const char* a_src;
+    {
+        const int row = quad * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        am = am < p.M ? am : p.M - 1;
+        a_src = reinterpret_cast<const char*>(p.A + (size_t)am * p.lda) + chunk * 16 + (size_t)(ks_beg + kg) * 64;
+    }
+    const char* w_src[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int f = quad + 4 * j;                 // fragment of the K-step: column tile f >> 1, plane f & 1
+        int nt = (n0 >> 5) + (f >> 1);
+        nt = nt < (p.N >> 5) ? nt : (p.N >> 5) - 1;
+        w_src[j] = reinterpret_cast<const char*>(p.Wimg) + (((size_t)nt * nks + ks_beg + kg) * 2 + (f & 1)) * 1024 + lane * 16;
+    }
+    auto issue_stage = [&](int st) {
+        const int sc = st < n_stages ? st : n_stages - 1;
+        char* slot_ = smem + (st % NS) * Geo::STAGE;
+        glds16(a_src + (size_t)sc * KS * 64, slot_ + kg * 4096 + quad * 1024);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            glds16(w_src[j] + (size_t)sc * KS * 2 * 1024, slot_ + Geo::A_STAGE + (kg * 4 * NB + quad + 4 * j) * 1024);
+    };
+
+    f32x16 acc[NB], accx[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = accx[b][i] = 0.f;
+    float amax = 0.f;
+    const int my_row = wm * 32 + r;
+    const int sw = (my_row >> 2) & 3;
+    const int a_off0 = kg * 4096 + my_row * 64 + (((2 * h) ^ sw) << 4), a_off1 = kg * 4096 + my_row * 64 + (((2 * h + 1) ^ sw) << 4);
+
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) issue_stage(st);
+    for (int st = 0; st < n_stages; ++st) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Geo::G * (NS - 2)) : "memory");   // own parts of stage st landed
+        __builtin_amdgcn_s_barrier();                                              // everybody's; stage st - 1 is free
+        issue_stage(st + NS - 1);
+        const char* slot_ = smem + (st % NS) * Geo::STAGE;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(slot_ + a_off0);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(slot_ + a_off1);
+        f16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = e < 4 ? x0[e] : x1[e - 4];
+            const _Float16 hi = (_Float16)x;
+            ah[e] = hi;
+            al[e] = (_Float16)((x - (float)hi) * kX3Scale);
+            amax = fmaxf(amax, fabsf(x));
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // fragment (column tile wn NB + b, plane) of K-step kg: column tile c = f >> 1 with f = 2 c + plane
+            const char* wb = slot_ + Geo::A_STAGE + (kg * 4 * NB + 2 * (wn * NB + b)) * 1024 + lane * 16;
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(wb);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(wb + 1024);
+            acc[b] = RAGB_WL_MFMA_F16(wh, ah, acc[b]);
+            accx[b] = RAGB_WL_MFMA_F16(wl, ah, accx[b]);
+            accx[b] = RAGB_WL_MFMA_F16(wh, al, accx[b]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last stages
+    if (p.range_flag && amax >= kF16Max) *p.range_flag = 1u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = __builtin_fmaf(accx[b][i], kX3Unscale, acc[b][i]);
+    if constexpr (KG > 1) {
+    __builtin_amdgcn_s_barrier();                       // every wave is done with the ring: it carries the partials now
+    float* red = reinterpret_cast<float*>(smem);        // [KG - 1][4 quadrants][NB][16][64]
+    if (kg > 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[((((kg - 1) * 4 + quad) * NB + b) * 16 + i) * 64 + lane] = acc[b][i];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] += red[((((g - 1) * 4 + quad) * NB + b) * 16 + i) * 64 + lane];
+    }
+    float* Cz = p.C + (split ? (size_t)kz * p.M * p.ldc : 0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        store_tile_rows(acc[b], m0 + wm * 32 + r, n0 + (wn * NB + b) * 32, h, p.M, p.N, p.bias, p.R, p.ldr, Cz, p.ldc, p.act,
+                        split);
+}
+
 }  // namespace ragb

@@ -44,10 +44,11 @@ struct rag_bert {
     std::vector<_Float16*> wx2;
     std::vector<__bf16*> wx;
     std::vector<_Float16*> wxf;
-    uint32_t* range_flag = nullptr;   // device word: a big-batch GEMM met |a| >= 65504 (or a weight did, at creation)
-    uint32_t* range_pin = nullptr;    // pinned host copy, read back with the results
+    uint32_t* range_pin = nullptr;    // pinned host word the GEMM kernels write themselves (posted store): a two-plane
+                                      // GEMM met |a| >= 65504 (or a weight did, at creation); read after a sync
     bool weights_fit_f16 = true;      // every GEMM weight is inside fp16's range: the two-plane images are valid
     bool force_x6 = false;            // this forward pass runs its big-batch GEMMs on the split-bf16 images
+    bool background = false;          // rag_bert_set_background
     long long range_events = 0;       // forward passes repeated on the split-bf16 path
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -128,7 +129,8 @@ struct WRef {
     const _Float16* wx2;   // two fp16 planes, fragment order (null: not available / not valid)
     const __bf16* wx;      // three bf16 planes, fragment order (null: not built)
     const _Float16* wxf;   // one fp16 plane, fragment order (RAG_GEMM_F16)
-    uint32_t* range_flag;  // the model's "outside fp16's range" word
+    uint32_t* range_flag;  // this pass's "outside fp16's range" word (pinned host memory the device writes)
+    bool background;       // rag_bert_set_background: small-batch GEMMs in their 32-KiB-LDS form
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel (sizes above 64 KiB need it)
@@ -156,6 +158,36 @@ int launch_wl(const ragb::GemmWlParams& g, hipStream_t st) {
     return RAG_OK;
 }
 
+// Small batches on the two-plane path: 64 x 64 tiles while they fit the chip in one round, 64 x 128 beyond that.
+int launch_ws(ragb::GemmWsParams g, int splits, int n_cus, hipStream_t st, bool background) {
+    const long long mt = (g.M + 63) / 64;
+    if (background) {   // kernels that fit beside another stream's resident workgroups: 32 KiB of LDS, four waves
+        g.splits = splits;
+        using Bg = ragb::WsGeom<1, 1>;
+        auto fn = &ragb::gemm_nt_ws_kernel<1, 1>;
+        int rc0 = ensure_lds(reinterpret_cast<const void*>(fn), Bg::LDS);
+        if (rc0) return rc0;
+        hipLaunchKernelGGL(fn, dim3((unsigned)ragb::ws_grid(g.M, g.N, 1, splits)), dim3(Bg::THREADS), Bg::LDS, st, g);
+        RAGC_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
+    const bool wide = mt * ((g.N + 63) / 64) * splits > n_cus;
+    g.splits = splits;
+    const dim3 grid((unsigned)ragb::ws_grid(g.M, g.N, wide ? 2 : 1, splits), 1, 1);
+    int rc;
+    if (wide) {
+        auto fn = &ragb::gemm_nt_ws_kernel<2>;
+        if ((rc = ensure_lds(reinterpret_cast<const void*>(fn), ragb::WsGeom<2>::LDS))) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(ragb::WsGeom<2>::THREADS), ragb::WsGeom<2>::LDS, st, g);
+    } else {
+        auto fn = &ragb::gemm_nt_ws_kernel<1>;
+        if ((rc = ensure_lds(reinterpret_cast<const void*>(fn), ragb::WsGeom<1>::LDS))) return rc;
+        hipLaunchKernelGGL(fn, grid, dim3(ragb::WsGeom<1>::THREADS), ragb::WsGeom<1>::LDS, st, g);
+    }
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 // Plain GEMM with fused epilogue.  Small M uses 64x64 tiles so the grid still covers the chip; big M
 // runs on the bf16 matrix cores with fp32 accuracy (split-bf16 image), or takes fp16 inputs when the
 // model was created with RAG_GEMM_F16, or stays on the fp32 MFMA (RAG_GEMM_F32_STRICT).
@@ -176,6 +208,8 @@ int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* b
         const ragb::GemmWlParams g{A, Wr.wxf, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
         return K <= 512 ? launch_wl<1, 1, 4, true>(g, st) : launch_wl<1, 2, 3, false>(g, st);
     }
+    if (M <= 1024 && Wr.wx2 && ldw == K && K % 64 == 0 && N % 32 == 0 && (lda % 4) == 0)
+        return launch_ws(ragb::GemmWsParams{A, Wr.wx2, bias, R, C, M, N, K, lda, ldr, ldc, act, K, 1, Wr.range_flag}, 1, n_cus, st, Wr.background);
     ragb::GemmParams g;
     g.A = A; g.W = W; g.bias = bias; g.R = R; g.C = C;
     g.M = M; g.N = N; g.K = K;
@@ -213,6 +247,27 @@ int launch_gemm_ln(const float* A, int lda, const WRef& Wr, int ldw, const float
     if (M <= 0) return RAG_OK;
     const float* W = Wr.w;
     int splits = 1;
+    if (M <= 1024 && Wr.wx2 && K % 64 == 0 && N % 32 == 0) {
+        // two-plane path: 64 x 64 tiles, one workgroup per CU; split K while that still adds workgroups to an
+        // under-filled chip (a split's K range stays a multiple of 64 and at least 128)
+        const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+        int sp = 1;
+        for (int c = 2; c <= kMaxSplits; ++c)
+            if (K % (64 * c) == 0 && K / c >= 128 && tiles * c <= n_cus) sp = c;
+        if (sp == 1) {
+            int rc = launch_ws(ragb::GemmWsParams{A, Wr.wx2, bias, R, part, M, N, K, lda, N, N, ragb::ACT_NONE, K, 1, Wr.range_flag},
+                               1, n_cus, st, Wr.background);
+            if (rc) return rc;
+            ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, 1, nullptr, nullptr, ln_g, ln_b, y, M, N, eps);
+        } else {
+            int rc = launch_ws(ragb::GemmWsParams{A, Wr.wx2, nullptr, nullptr, part, M, N, K, lda, 0, N, ragb::ACT_NONE, K / sp, sp,
+                                                  Wr.range_flag}, sp, n_cus, st, Wr.background);
+            if (rc) return rc;
+            ragb::splitk_bias_res_ln_kernel<<<dim3((M + 3) / 4), dim3(256), 0, st>>>(part, sp, bias, R, ln_g, ln_b, y, M, N, eps);
+        }
+        RAGC_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
     if (M <= 1024) {
         // One wave multiplies one 32x32 output tile over its K range, and the chip has 4 * n_cus SIMDs:
         // pick the split that minimises (rounds of wave-tiles) x (K per split), e.g. 336 tiles at
@@ -269,7 +324,7 @@ size_t out_elems(const rag_bert_config& c, int out_kind, long long nseq, long lo
 }
 
 int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu, int nseq, int T, int max_len,
-                   int out_kind, int normalize, float* out, hipStream_t st) {
+                   int out_kind, int normalize, float* out, hipStream_t st, uint32_t* range_flag) {
     using namespace ragb;
     const rag_bert_config& c = h->cfg;
     const int H = c.hidden, I = c.intermediate, heads = c.n_heads, dh = H / heads;
@@ -325,7 +380,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             const size_t at = (size_t)4 * l + i;
             const bool two_plane = !h->force_x6 && h->weights_fit_f16 && !h->wx2.empty();
             return WRef{lw[wsrc[i]], two_plane ? h->wx2[at] : nullptr, h->wx.empty() ? nullptr : h->wx[at],
-                        h->wxf.empty() ? nullptr : h->wxf[at], h->range_flag};
+                        h->wxf.empty() ? nullptr : h->wxf[at], range_flag, h->background};
         };
         // QKV projection
         rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st, h->n_cus);
@@ -393,7 +448,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
                 RAGC_HIP_TRY(hipGetLastError());
             }
-            rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr, nullptr, nullptr}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
+            rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr, nullptr, nullptr, false}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
             if (rc) return rc;
             const bool probs = out_kind == RAG_BERT_OUT_PROBS;
             head_out_kernel<<<dim3(nseq, c.n_labels), dim3(64), 0, st>>>(h->pooled2, hw[2], hw[3], probs ? h->logits : out,
@@ -449,7 +504,7 @@ int build_images(rag_bert* h, int kind) {
                 ragb::pack_f16_frag_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wxf[at]);
             } else {
                 h->wx2[at] = static_cast<_Float16*>(img);
-                ragb::pack_f16x2_frag_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wx2[at], h->range_flag);
+                ragb::pack_f16x2_frag_kernel<<<grid, dim3(256), 0, h->stream>>>(W, N, K, K, h->wx2[at], h->range_pin);
             }
         }
     }
@@ -506,9 +561,7 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
     const char* va = getenv("RAG_AMD_VALU_ATTENTION");
     h->valu_attention = va && *va == '1';
-    if (hipMalloc(reinterpret_cast<void**>(&h->range_flag), sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(h->range_flag, 0, sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         rag_bert_destroy(h);
         return ragc_fail(RAG_ERR_OOM, "allocation of the range flag failed");
     }
@@ -524,14 +577,9 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     }
     if (c.gemm_mode == RAG_GEMM_F32) {
         // a weight outside fp16's range (never seen in a BERT-family checkpoint) invalidates the two-plane images
-        uint32_t flag = 0;
-        if (hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) {
-            rag_bert_destroy(h);
-            return ragc_fail(RAG_ERR_HIP, "reading the range flag failed");
-        }
-        if (flag) {
+        if (*h->range_pin) {   // (build_images has synchronised the stream the pack kernels ran on)
             h->weights_fit_f16 = false;
-            (void)hipMemset(h->range_flag, 0, sizeof(uint32_t));
+            *h->range_pin = 0;
             if ((rc = build_images(h, 0))) {
                 rag_bert_destroy(h);
                 return rc;
@@ -558,7 +606,6 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
             if (p) (void)hipFree(p);
         for (_Float16* p : h->wxf)
             if (p) (void)hipFree(p);
-        if (h->range_flag) (void)hipFree(h->range_flag);
         if (h->range_pin) (void)hipHostFree(h->range_pin);
         if (h->stage_pin) (void)hipHostFree(h->stage_pin);
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);
@@ -572,7 +619,7 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
 extern "C" int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* type_ids_dev,
                                        const int32_t* cu_seqlens_dev, int32_t nseq, int32_t total_tokens,
                                        int32_t max_seq_len, int32_t out_kind, int32_t normalize, float* out_dev,
-                                       void* stream) {
+                                       uint32_t* range_flag, void* stream) {
     int rc = check_forward(h, nseq, out_kind);
     if (rc) return rc;
     if (!ids_dev || !cu_seqlens_dev || !out_dev || total_tokens <= 0 || max_seq_len <= 0)
@@ -580,7 +627,7 @@ extern "C" int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, cons
     RagcDeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     return forward_locked(h, ids_dev, type_ids_dev, cu_seqlens_dev, nseq, total_tokens, max_seq_len, out_kind, normalize,
-                          out_dev, (hipStream_t)stream);
+                          out_dev, (hipStream_t)stream, range_flag ? range_flag : h->range_pin);
 }
 
 namespace {
@@ -603,7 +650,7 @@ int check_host_batch(const rag_bert* h, const int32_t* cu_seqlens, int nseq, int
 
 extern "C" int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const int32_t* type_ids,
                                           const int32_t* cu_seqlens, int32_t nseq, int32_t out_kind, int32_t normalize,
-                                          float* out_dev, void** stream_out) {
+                                          float* out_dev, uint32_t* range_flag, void** stream_out) {
     int rc = check_forward(h, nseq, out_kind);
     if (rc) return rc;
     if (!ids || !cu_seqlens || !out_dev || !stream_out) return ragc_fail(RAG_ERR_INVALID_ARG, "null buffer");
@@ -642,7 +689,7 @@ extern "C" int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const
     RAGC_HIP_TRY(hipEventRecord(h->stage_event, st));
     h->stage_used = true;
     rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind, normalize,
-                        out_dev, st);
+                        out_dev, st, range_flag ? range_flag : h->range_pin);
     if (rc) return rc;
     *stream_out = (void*)st;
     return RAG_OK;
@@ -677,21 +724,21 @@ extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* 
     RAGC_HIP_TRY(hipMemcpyAsync(h->ids_dev, ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
     if (type_ids) RAGC_HIP_TRY(hipMemcpyAsync(h->types_dev, type_ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
     RAGC_HIP_TRY(hipMemcpyAsync(h->cu_dev, cu_seqlens, (size_t)(nseq + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    *h->range_pin = 0;   // (the stream is idle: synchronised above)
     rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind, normalize,
-                        h->out_dev, st);
+                        h->out_dev, st, h->range_pin);
     if (rc) return rc;
     RAGC_HIP_TRY(hipMemcpyAsync(out, h->out_dev, n_out * sizeof(float), hipMemcpyDeviceToHost, st));
-    RAGC_HIP_TRY(hipMemcpyAsync(h->range_pin, h->range_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RAGC_HIP_TRY(hipStreamSynchronize(st));
     if (*h->range_pin) {
         // An activation outside fp16's range (|x| >= 65504) went through the two-plane GEMMs: that pass is void.
-        // Repeat it on the split-bf16 images (fp32's exponent range), built now if this is the first time.
+        // Repeat it with fp32's exponent range: big batches on the split-bf16 images (built now if this is the
+        // first time), small ones on the fp32 MFMA.
         *h->range_pin = 0;
-        RAGC_HIP_TRY(hipMemsetAsync(h->range_flag, 0, sizeof(uint32_t), st));
         if ((rc = build_images(h, 0))) return rc;
         h->force_x6 = true;
         rc = forward_locked(h, h->ids_dev, type_ids ? h->types_dev : nullptr, h->cu_dev, nseq, T, max_len, out_kind,
-                            normalize, h->out_dev, st);
+                            normalize, h->out_dev, st, h->range_pin);
         h->force_x6 = false;
         if (rc) return rc;
         ++h->range_events;
@@ -701,17 +748,22 @@ extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* 
     return RAG_OK;
 }
 
+extern "C" int rag_bert_set_background(rag_bert* h, int32_t on) {
+    if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->background = on != 0;
+    return RAG_OK;
+}
+
 extern "C" int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pending) {
     if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
     RagcDeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     if (repeated_passes) *repeated_passes = h->range_events;
-    if (pending) {   // a pass of one of the asynchronous entry points raised the flag since it was last taken
-        uint32_t flag = 0;
+    if (pending) {   // an asynchronous pass that used the handle's own word raised it since it was last taken
         RAGC_HIP_TRY(hipDeviceSynchronize());
-        RAGC_HIP_TRY(hipMemcpy(&flag, h->range_flag, sizeof flag, hipMemcpyDeviceToHost));
-        if (flag) RAGC_HIP_TRY(hipMemset(h->range_flag, 0, sizeof flag));
-        *pending = flag ? 1 : 0;
+        *pending = *h->range_pin ? 1 : 0;
+        *h->range_pin = 0;
     }
     return RAG_OK;
 }

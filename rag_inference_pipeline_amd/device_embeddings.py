@@ -21,7 +21,8 @@ import numpy as np
 class DeviceEmbeddings:
     ndim = 2
 
-    def __init__(self, tensor: Any, stream: int, device: int, producer_alive: Any = None) -> None:
+    def __init__(self, tensor: Any, stream: int, device: int, producer_alive: Any = None, range_word: Any = None,
+                 recompute: Any = None) -> None:
         self._tensor = tensor          # (n, d) float32, C-contiguous, on `device`; filled by work enqueued on `stream`
         self.stream = int(stream)      # hipStream_t of the producer: consumers enqueue behind it or synchronise it
         self.device = int(device)
@@ -32,6 +33,11 @@ class DeviceEmbeddings:
         # waited for the stream since (`settled`) and waits itself, once, if it is dropped unconsumed.
         self._producer_alive = producer_alive or (lambda: True)
         self._settled = False
+        # The encoder's GEMMs write fp32 operands as two fp16 numbers; an activation outside fp16's range voids the
+        # pass and the kernels say so in this pinned word (include/rag_amd.h rag_bert_forward_device).  `recompute`
+        # (set by the embedder) then yields the same embeddings through the host path, which has fp32's range.
+        self._range_word = range_word
+        self.recompute = recompute
 
     @property
     def data_ptr(self) -> int:
@@ -43,6 +49,10 @@ class DeviceEmbeddings:
     def settled(self) -> None:
         """The consumer has synchronised `stream` behind this batch (rag_index_search_device_host_out does)."""
         self._settled = True
+
+    def valid(self) -> bool:
+        """After the producer's stream has been waited for: False if the pass left fp16's range (use recompute())."""
+        return self._range_word is None or int(self._range_word[0]) == 0
 
     def _wait(self) -> None:
         if not self._settled and self._producer_alive():
@@ -60,6 +70,8 @@ class DeviceEmbeddings:
     def numpy(self) -> np.ndarray:
         """The embeddings on the host (waits for the producer's stream)."""
         self._wait()
+        if not self.valid() and self.recompute is not None:
+            return self.recompute()
         return self._tensor.cpu().numpy()
 
     def astype(self, dtype: Any) -> np.ndarray:   # a consumer written for the reference's arrays still works

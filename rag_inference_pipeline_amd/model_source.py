@@ -100,6 +100,40 @@ class HashTokenizer:
         return out_ids, out_types
 
 
+    def encode_pairs_packed(self, first: Sequence[str], second: Sequence[str], max_length: int, with_types: bool = True):
+        """encode_pairs() straight into the packed (ids, token types, cu_seqlens) arrays the transformer takes, in one
+        native call (rag_hash_encode_pairs).  None when a text is not ASCII or the library is not there: the caller
+        then uses encode_pairs()."""
+        import ctypes as C
+
+        try:
+            from . import _native
+            lib = _native.lib()
+        except Exception:  # noqa: BLE001
+            return None
+        n = len(first)
+        try:
+            fa = [t.encode("ascii") for t in first]
+            fb = [t.encode("ascii") for t in second]
+        except UnicodeEncodeError:
+            return None
+        la = np.fromiter(map(len, fa), dtype=np.int64, count=n)
+        lb = np.fromiter(map(len, fb), dtype=np.int64, count=n)
+        cap = int(la.sum() + lb.sum()) + 4 * n + 4
+        ids = np.empty(cap, dtype=np.int32)
+        types = np.empty(cap, dtype=np.int32) if with_types else None
+        cu = np.empty(n + 1, dtype=np.int32)
+        i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        total = lib.rag_hash_encode_pairs(
+            (C.c_char_p * n)(*fa), la.ctypes.data_as(i64p), (C.c_char_p * n)(*fb), lb.ctypes.data_as(i64p), n,
+            int(max_length), 1 if self.roberta else 0, int(self._first), int(self.vocab_size - self._first),
+            int(self.cls_id), int(self.sep_id), ids.ctypes.data_as(i32p),
+            types.ctypes.data_as(i32p) if types is not None else None, cu.ctypes.data_as(i32p), cap)
+        if total < 0:
+            return None
+        return ids[:total], (types[:total] if types is not None else None), cu
+
+
 class HFTokenizer:
     """A Hugging Face tokenizer loaded from local files (tokenizer.json / vocab.txt / sentencepiece)."""
 

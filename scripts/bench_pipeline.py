@@ -15,7 +15,8 @@ from rag_inference_pipeline_amd.components.document_store import DocumentStore
 from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
 from rag_inference_pipeline_amd.components.reranker import Reranker
 from rag_inference_pipeline_amd.config import PipelineSettings
-from rag_inference_pipeline_amd.flat_index import FlatIndex
+from rag_inference_pipeline_amd.components.faiss_store import FAISSStore
+from rag_inference_pipeline_amd.flat_index import SCREEN_FP16, FlatIndex
 from rag_inference_pipeline_amd.retrieval_executor import RetrievalExecutor
 from rag_inference_pipeline_amd.schemas import PendingRequest
 from rag_inference_pipeline_amd.telemetry import stage_timers
@@ -52,16 +53,17 @@ settings = PipelineSettings(DOCUMENTS_DIR=os.path.join(tmp, "documents"), DOCUME
                             RAG_AMD_RERANKER_DTYPE=a.dtype)
 
 
-class SyntheticStore:  # FAISSStore surface over a synthetic corpus (no 1.5 GB file round trip)
-    is_loaded = True
-    def __init__(self, n, d):
-        self.index = FlatIndex(d); self.index.add_synthetic(n, 1234)
-    def search(self, emb, k):
-        return self.index.search(emb.astype("float32"), k)
+class SyntheticStore(FAISSStore):  # the product's FAISSStore (its search(), two-stage default, device hand-off) over a
+    def __init__(self, settings, n, d):   # synthetic corpus generated on the GPU (no 1.5 GB file round trip)
+        super().__init__(settings)
+        idx = FlatIndex(d); idx.add_synthetic(n, 1234)
+        if getattr(settings, "faiss_two_stage", True):
+            idx.set_screening(SCREEN_FP16)
+        self._index, self._ntotal, self._is_loaded = idx, n, True
 
 reg = ComponentRegistry()
 emb = EmbeddingGenerator(settings); reg.register("embedding_generator", emb, emb.load)
-reg.register("faiss_store", SyntheticStore(a.rows, 384))
+reg.register("faiss_store", SyntheticStore(settings, a.rows, 384))
 reg.register("document_store", DocumentStore(settings))
 if a.rerank:
     rr = Reranker(settings); reg.register("reranker", rr, rr.load)

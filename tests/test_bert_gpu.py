@@ -229,3 +229,55 @@ def test_values_outside_fp16_range_take_the_three_plane_path(gpu_required):
     assert ev == 0                                                   # known at creation: no pass is ever repeated
     np.testing.assert_allclose(got, want, atol=3e-4, rtol=1e-5)
     assert np.abs(base - got).max() > 0
+
+
+def test_small_batches_outside_fp16_range_are_flagged_and_repeated(gpu_required):
+    """The query encoder's batch (<= 1024 tokens) runs the same two-plane GEMMs on 64-row tiles.  Host path: a pass
+    that meets |x| >= 65504 is repeated on the fp32 MFMA.  Device hand-off: the pass cannot repeat itself, its pinned
+    flag word says the embeddings are void (DeviceEmbeddings.valid()) and numpy() goes through `recompute`."""
+    cfg = _small(BertConfig.minilm_l6())
+    w = random_weights(cfg, 31)
+    b = w["layer0.ffn_in_b"].copy()
+    b[:5] = 1.0e5
+    w_act = dict(w, **{"layer0.ffn_in_b": b})
+    rng = np.random.default_rng(31)
+    seqs = _seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size)
+    strict_cfg = _small(BertConfig.minilm_l6())
+    strict_cfg.gemm_dtype = "f32_strict"
+    for weights, flagged in ((w, False), (w_act, True)):
+        strict = BertModel(strict_cfg, weights)
+        want = strict.embed(seqs)
+        strict.close()
+        model = BertModel(cfg, weights)
+        got = model.embed(seqs)                                   # host path: repeats by itself
+        np.testing.assert_allclose(got, want, atol=2e-5)
+        assert model.range_events()[0] == (1 if flagged else 0)
+        dev = model.embed_to_device(seqs)
+        dev.recompute = lambda: model.embed(seqs)
+        arr = dev.numpy()
+        assert dev.valid() == (not flagged)
+        np.testing.assert_allclose(arr, want, atol=2e-5)          # through recompute when the pass was void
+        if not flagged:
+            np.testing.assert_array_equal(arr.view(np.uint32), got.view(np.uint32))
+        model.close()
+
+
+def test_background_mode_gives_the_same_embeddings(gpu_required):
+    """rag_bert_set_background: the small-batch GEMMs in their 32-KiB-LDS form (one K-step per stage, four waves) — what
+    bench.py's pipelined leg runs under the corpus scan — against the oracle and the default form."""
+    cfg = _small(BertConfig.bge_base())
+    cfg.n_layers = 3
+    w = random_weights(cfg, 41)
+    rng = np.random.default_rng(41)
+    seqs = _seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size)
+    model = BertModel(cfg, w)
+    base = model.embed(seqs)
+    model.set_background(True)
+    bg = model.embed(seqs)
+    model.set_background(False)
+    again = model.embed(seqs)
+    model.close()
+    want = obert.embed(cfg, w, seqs)
+    np.testing.assert_allclose(bg, want, atol=1e-5)
+    np.testing.assert_allclose(base, want, atol=1e-5)
+    np.testing.assert_array_equal(again.view(np.uint32), base.view(np.uint32))   # switching back restores the default form

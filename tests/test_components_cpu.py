@@ -187,3 +187,34 @@ def test_build_index_does_not_take_torchruns_default_run_id_as_a_build_id(monkey
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-4711")   # a real id is used: the call gets past the check
     with pytest.raises(FileNotFoundError, match="Document database"):
         build_index(str(tmp_path), "synthetic:all-MiniLM-L6-v2", str(tmp_path / "x.f32"), rank=1, world=2)
+
+
+def test_native_pair_encoder_equals_the_python_stand_in_tokenizer():
+    """rag_hash_encode_pairs (csrc/rag_text.cpp) against HashTokenizer.encode_pairs + pack_sequences: same ids, token
+    types and sequence boundaries for ASCII text — punctuation, control characters, every whitespace Python's `\\s`
+    knows, empty sides, truncation down to nothing, BERT and RoBERTa framing; non-ASCII text is declined (None)."""
+    from rag_inference_pipeline_amd.bert import pack_sequences
+
+    rng = np.random.default_rng(3)
+    alphabet = [chr(c) for c in range(1, 128)]
+    words = ["Retrieval", "augmented_generation", "x1", "don't", "3.14", "(a-b)", "GPU", "\x1c", "\x0b", "tab\there", "_"]
+
+    def text():
+        parts = []
+        for _ in range(int(rng.integers(0, 40))):
+            parts.append(str(rng.choice(words)) if rng.random() < 0.7 else "".join(rng.choice(alphabet, size=int(rng.integers(1, 6)))))
+        return str(rng.choice([" ", "  ", "\n", "\t "])).join(parts)
+
+    for roberta, vocab in ((False, 30522), (True, 250002), (False, 500)):
+        tok = HashTokenizer(vocab, roberta=roberta)
+        first, second = [text() for _ in range(120)], [text() for _ in range(120)]
+        first[3], second[4], second[3] = "", "", ""
+        for max_len in (512, 40, 7, 4, 3, 0):
+            ids, types = tok.encode_pairs(first, second, max_len)
+            want = pack_sequences(ids, types)
+            got = tok.encode_pairs_packed(first, second, max_len, True)
+            assert got is not None
+            for g, w in zip(got, want):
+                np.testing.assert_array_equal(g, w)
+            assert tok.encode_pairs_packed(first, second, max_len, False)[1] is None
+    assert HashTokenizer(30522).encode_pairs_packed(["café"], ["x"], 16) is None
