@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
-TRAFFIC_FILE = "r02_scan_hbm_traffic.json"  # PMC pass of this workload (profiles/README.md says how it was collected)
+TRAFFIC_FILE = "r03_scan_hbm_traffic.json"  # PMC pass of this workload (profiles/README.md says how it was collected)
 
 # xor of the returned ids for the default workload (rows, dim, batch, k, seed), as produced by the
 # 1-GPU run that the full-size parity test checks against the oracle; sharded runs must reproduce it
