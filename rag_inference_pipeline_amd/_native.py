@@ -18,7 +18,7 @@ _CSRC = os.path.join(_PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("RAG_AMD_LIB") or os.path.join(_CSRC, "librag_amd.so")  # override: experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "rag_amd.h")
 _SOURCES = ["rag_amd.hip", "rag_bert.hip", "rag_lz4.cpp", "rag_text.cpp"]
-_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "gemm_wl.hip.h", "rag_common.h",
+_DEPS = ["rag_amd.hip", "flat_kernels.hip.h", "rag_bert.hip", "bert_kernels.hip.h", "gemm_wl.hip.h", "gemm_wt.hip.h", "bert_tiled.hip.h", "rag_common.h",
          "rag_lz4.cpp", "rag_text.cpp"]
 
 RAG_OK = 0

@@ -36,6 +36,7 @@ struct rag_bert {
     int device = 0;
     int n_cus = 256;
     bool valu_attention = false;  // RAG_AMD_VALU_ATTENTION=1: the VALU attention kernel (A/B checks)
+    bool row_major_only = false;  // RAG_AMD_ROW_MAJOR=1: RAG_GEMM_F16 keeps fp32 row-major activations (A/B checks)
     std::vector<const float*> w;
     // Fragment-order images of the four GEMM weights of every layer, owned here (gemm_wl.hip.h):
     //   wx2  RAG_GEMM_F32: two fp16 planes (hi, scaled lo) — the default big-batch path
@@ -95,7 +96,7 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
             *b = nullptr;
         }
         h->ws_tokens = 0;
-        const long long t = tokens + tokens / 8;
+        const long long t = (tokens + tokens / 8 + 31) & ~31LL;   // (whole 32-token row blocks: the tiled layout's unit)
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->x), (size_t)t * c.hidden * sizeof(float)));
         // y doubles as the split-K slab area of the small-M path (kMaxSplits slabs)
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y), (size_t)std::max<long long>(t, 8 * std::min<long long>(t, 1152)) * c.hidden * sizeof(float)));
@@ -156,6 +157,26 @@ int launch_wl(const ragb::GemmWlParams& g, hipStream_t st) {
     hipLaunchKernelGGL(fn, dim3(ragb::xcd_grid(g.M, g.N, 128, 128)), dim3(256), Geo::LDS, st, g);
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
+}
+
+template <int AK, int NW, int NB, int KS, int NS, int OCC>
+int launch_wt(const ragb::GemmWtParams& g, hipStream_t st) {
+    using Geo = ragb::WtGeom<AK, NW, NB, KS, NS>;
+    auto fn = &ragb::gemm_nt_wt_kernel<AK, NW, NB, KS, NS, OCC, 0>;
+    int rc = ensure_lds(reinterpret_cast<const void*>(fn), Geo::LDS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fn, dim3(ragb::xcd_grid(g.M, g.N, Geo::TM, Geo::TN)), dim3(Geo::THREADS), Geo::LDS, st, g);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+// GEMM over fp16 activations in fragment order (gemm_wt.hip.h): 256 x 128 tiles; one 16-deep K-step per stage and
+// three workgroups per CU, or two steps per stage and two workgroups for long K (scripts/exp/gemm_wh_bench.hip).
+int launch_gemm_t16(const _Float16* A, int lda, const _Float16* Wimg, const float* bias, const _Float16* R, int ldr,
+                    _Float16* C, int ldc, int M, int N, int K, int act, hipStream_t st) {
+    const ragb::GemmWtParams g{A, Wimg, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
+    if (K >= 1536 && K % 32 == 0) return launch_wt<1, 8, 4, 2, 3, 2>(g, st);
+    return launch_wt<1, 8, 4, 1, 4, 3>(g, st);
 }
 
 // Small batches on the two-plane path: 64 x 64 tiles while they fit the chip in one round, 64 x 128 beyond that.
@@ -355,8 +376,6 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     ep.out = h->x;
     ep.T = T; ep.nseq = nseq; ep.H = H; ep.pos_offset = c.pos_offset; ep.max_pos = c.max_positions;
     ep.vocab = c.vocab_size; ep.type_vocab = c.type_vocab > 0 ? c.type_vocab : 1; ep.eps = c.ln_eps;
-    embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
-    RAGC_HIP_TRY(hipGetLastError());
 
     const int act = map_act(c.act);
     const float scale = 1.0f / sqrtf((float)dh);
@@ -373,6 +392,26 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     // holds them within 1e-5 on both sides of the 1024-row switch).
     const bool first_only_out = out_kind == RAG_BERT_OUT_CLS || out_kind == RAG_BERT_OUT_LOGITS || out_kind == RAG_BERT_OUT_PROBS;
     bool compact = false;  // h->pooled holds the final hidden state of the first tokens, one row per sequence
+    // RAG_GEMM_F16, big batches: activations are fp16 in MFMA-fragment order from the embeddings to the last layer
+    // (gemm_wt.hip.h, bert_tiled.hip.h); the first-token tail of the last layer and the heads continue in row-major fp32.
+    const bool tiled = c.gemm_mode == RAG_GEMM_F16 && T > 1024 && !h->wxf.empty() && !h->valu_attention && !h->row_major_only;
+    using half_t = _Float16;
+    half_t* xh = reinterpret_cast<half_t*>(h->x);
+    half_t* parth = reinterpret_cast<half_t*>(h->y);
+    half_t* qkvh = reinterpret_cast<half_t*>(h->qkv);
+    half_t* ctxh = reinterpret_cast<half_t*>(h->ctx);
+    half_t* ffnh = reinterpret_cast<half_t*>(h->ffn);
+    const int nrb = (T + 31) / 32;
+    const int row_lds = 32 * (H + ragb::kRowPad) * (int)sizeof(float);
+    if (tiled) {
+        if ((rc = ensure_lds(reinterpret_cast<const void*>(&embed_ln_tiled_kernel<half_t>), row_lds))) return rc;
+        if ((rc = ensure_lds(reinterpret_cast<const void*>(&ln_tiled_kernel<half_t>), row_lds))) return rc;
+        hipLaunchKernelGGL(embed_ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, ep, xh);
+    } else {
+        embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
+    }
+    RAGC_HIP_TRY(hipGetLastError());
+
     for (int l = 0; l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
         const int wsrc[4] = {0, 2, 6, 8};  // qkv_w, attn_out_w, ffn_in_w, ffn_out_w in the layer's table
@@ -382,10 +421,52 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             return WRef{lw[wsrc[i]], two_plane ? h->wx2[at] : nullptr, h->wx.empty() ? nullptr : h->wx[at],
                         h->wxf.empty() ? nullptr : h->wxf[at], range_flag, h->background};
         };
+        const bool last_first_only = first_only_out && l == c.n_layers - 1 && !h->valu_attention && nseq < T;
+        if (tiled) {
+            const size_t at = (size_t)4 * l;
+            rc = launch_gemm_t16(xh, H, h->wxf[at + 0], lw[1], nullptr, 0, qkvh, 3 * H, T, 3 * H, H, ACT_NONE, st);
+            if (rc) return rc;
+            if (last_first_only) {
+                // first tokens only: attention writes row-major fp32 rows, and the rest of the layer is the row-major tail
+                const dim3 fgrid(1, heads, nseq);
+                if (dh == 32)
+                    attention_tiled_kernel<32, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                else
+                    attention_tiled_kernel<64, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                RAGC_HIP_TRY(hipGetLastError());
+                const int total = nseq * H;
+                gather_rows_tiled_kernel<half_t><<<dim3((total + 255) / 256), dim3(256), 0, st>>>(xh, cu, h->pooled, nseq, H);
+                RAGC_HIP_TRY(hipGetLastError());
+                rc = launch_gemm_ln(h->ctx, H, wref(1), H, lw[3], h->pooled, h->y, lw[4], lw[5], h->pooled, nseq, H, H, c.ln_eps, h->n_cus, st);
+                if (rc) return rc;
+                rc = launch_gemm(h->pooled, H, wref(2), H, lw[7], nullptr, 0, h->ffn, I, nseq, I, H, act, st, h->n_cus);
+                if (rc) return rc;
+                rc = launch_gemm_ln(h->ffn, I, wref(3), I, lw[9], h->pooled, h->y, lw[10], lw[11], h->pooled, nseq, H, I, c.ln_eps, h->n_cus, st);
+                if (rc) return rc;
+                compact = true;
+                break;
+            }
+            if (dh == 32)
+                attention_tiled_kernel<32, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            else
+                attention_tiled_kernel<64, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            RAGC_HIP_TRY(hipGetLastError());
+            // attention output projection + bias + residual (fp16, in the epilogue), LayerNorm back into x
+            rc = launch_gemm_t16(ctxh, H, h->wxf[at + 1], lw[3], xh, H, parth, H, T, H, H, ACT_NONE, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, parth, lw[4], lw[5], xh, T, H, c.ln_eps);
+            RAGC_HIP_TRY(hipGetLastError());
+            rc = launch_gemm_t16(xh, H, h->wxf[at + 2], lw[7], nullptr, 0, ffnh, I, T, I, H, act, st);
+            if (rc) return rc;
+            rc = launch_gemm_t16(ffnh, I, h->wxf[at + 3], lw[9], xh, H, parth, H, T, H, I, ACT_NONE, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, parth, lw[10], lw[11], xh, T, H, c.ln_eps);
+            RAGC_HIP_TRY(hipGetLastError());
+            continue;
+        }
         // QKV projection
         rc = launch_gemm(h->x, H, wref(0), H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st, h->n_cus);
         if (rc) return rc;
-        const bool last_first_only = first_only_out && l == c.n_layers - 1 && !h->valu_attention && nseq < T;
         if (last_first_only) {
             const dim3 fgrid(1, heads, nseq);
             if (dh == 32)
@@ -430,12 +511,20 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
 
     switch (out_kind) {
         case RAG_BERT_OUT_HIDDEN:
+            if (tiled) {
+                if ((rc = ensure_lds(reinterpret_cast<const void*>(&untile_kernel<half_t>), row_lds))) return rc;
+                hipLaunchKernelGGL(untile_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, xh, out, T, H);
+                RAGC_HIP_TRY(hipGetLastError());
+                break;
+            }
             RAGC_HIP_TRY(hipMemcpyAsync(out, h->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, st));
             break;
         case RAG_BERT_OUT_MEAN:
         case RAG_BERT_OUT_CLS:
             if (compact)
                 pool_kernel<<<dim3(nseq), dim3(256), 0, st>>>(h->pooled, cu, out, H, 2, normalize);
+            else if (tiled)
+                pool_tiled_kernel<half_t><<<dim3(nseq), dim3(256), 0, st>>>(xh, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
             else
                 pool_kernel<<<dim3(nseq), dim3(256), 0, st>>>(h->x, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
             RAGC_HIP_TRY(hipGetLastError());
@@ -445,7 +534,10 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             const float* const* hw = w + kEmbEntries + kPerLayer * c.n_layers;
             if (!compact) {
                 const int total = nseq * H;
-                gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
+                if (tiled)
+                    gather_rows_tiled_kernel<half_t><<<dim3((total + 255) / 256), dim3(256), 0, st>>>(xh, cu, h->pooled, nseq, H);
+                else
+                    gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
                 RAGC_HIP_TRY(hipGetLastError());
             }
             rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr, nullptr, nullptr, false}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
@@ -561,6 +653,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cus = prop.multiProcessorCount;
     const char* va = getenv("RAG_AMD_VALU_ATTENTION");
     h->valu_attention = va && *va == '1';
+    const char* rm = getenv("RAG_AMD_ROW_MAJOR");
+    h->row_major_only = rm && *rm == '1';
     if (hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         rag_bert_destroy(h);
         return ragc_fail(RAG_ERR_OOM, "allocation of the range flag failed");

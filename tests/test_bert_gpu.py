@@ -159,6 +159,49 @@ def test_cross_encoder_fp16_gemm_mode_tracks_fp32_oracle(gpu_required):
     np.testing.assert_allclose(probs16, obert.classify(cfg, w, seqs, types), atol=5e-3)
 
 
+def test_fp16_mode_big_batches_run_on_fragment_ordered_fp16_activations(gpu_required, monkeypatch):
+    """RAG_GEMM_F16 above 1024 tokens: activations are fp16 in MFMA-fragment order from the embeddings to the last
+    layer (csrc/gemm_wt.hip.h, bert_tiled.hip.h) — the arithmetic of a .half() model (reference reranker.py:91-93).
+    Every output kind is held against the fp32 oracle within fp16's rounding (hidden states are O(1): 3e-2 is ~15
+    half-precision ulps after six layers) and against the same mode on row-major fp32 activations
+    (RAG_AMD_ROW_MAJOR=1, the round-2 data path); a ragged token count, sequences that straddle 32-token row
+    blocks, mean pooling, first-token pooling, both DH."""
+    for cfg_fn, seed in ((BertConfig.ms_marco_minilm_l6, 21), (BertConfig.bge_base, 22)):
+        cfg = _small(cfg_fn())
+        cfg.n_layers = min(cfg.n_layers, 3)
+        cfg.gemm_dtype = "f16"
+        w = random_weights(cfg, seed)
+        if "head_out_w" in w:
+            w["head_out_w"] = (w["head_out_w"] * 20).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        seqs = _seqs(rng, rng.integers(5, 71, size=61), cfg.vocab_size)   # ~2300 tokens
+        if sum(map(len, seqs)) % 32 == 0:                                 # ... and never whole row blocks
+            seqs += _seqs(rng, [7], cfg.vocab_size)
+        assert sum(map(len, seqs)) > 1024 and sum(map(len, seqs)) % 32 != 0
+        types = [[0] * 3 + [1] * (len(s) - 3) for s in seqs]
+        tiled = BertModel(cfg, w)
+        monkeypatch.setenv("RAG_AMD_ROW_MAJOR", "1")
+        rowm = BertModel(cfg, w)
+        monkeypatch.delenv("RAG_AMD_ROW_MAJOR")
+        want_h = np.concatenate(obert.hidden_states(cfg, w, seqs, types))
+        got_h, ref_h = tiled.hidden_states(seqs, types), rowm.hidden_states(seqs, types)
+        scale = max(1.0, np.abs(want_h).max())
+        assert np.abs(got_h - want_h).max() < 3e-2 * scale, np.abs(got_h - want_h).max()
+        assert np.abs(got_h - ref_h).max() < 3e-2 * scale
+        assert np.abs(got_h - ref_h).max() > 0          # and it really is another data path
+        for normalize in (True, False):
+            want_e = obert.embed(cfg, w, seqs, types, normalize=normalize)
+            got_e = tiled.embed(seqs, types, normalize=normalize)
+            assert np.abs(got_e - want_e).max() < 2e-2 * max(1.0, np.abs(want_e).max())
+        if cfg.head != "none":
+            want_l = obert.classify(cfg, w, seqs, types, sigmoid=False)
+            got_l = tiled.classify(seqs, types, sigmoid=False)
+            assert np.abs(got_l - want_l).max() < 3e-2 * max(1.0, np.abs(want_l).max())
+            np.testing.assert_allclose(tiled.classify(seqs, types), obert.classify(cfg, w, seqs, types), atol=5e-3)
+        tiled.close()
+        rowm.close()
+
+
 def test_split_bf16_gemms_keep_fp32_accuracy(gpu_required):
     """Default big-batch GEMMs run on the bf16 matrix cores (three-way exact split, six products):
     hidden states must be as close to a float64 evaluation as the fp32-MFMA path is."""
