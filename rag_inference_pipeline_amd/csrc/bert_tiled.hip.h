@@ -116,30 +116,87 @@ __global__ __launch_bounds__(256) void embed_ln_tiled_kernel(const EmbedParams p
     lds_to_block(rows, out, rb, p.H, tid);
 }
 
-// y = LayerNorm(x) per token; x and y tiled (may be the same buffer: a row block is read whole before it is written).
+// a lane's eight values of fragment (rb, ks): token 32 rb + (lane & 31), features 16 ks + 8 (lane >> 5) + 0..7
 template <typename E>
-__global__ __launch_bounds__(256) void ln_tiled_kernel(const E* x, const float* g, const float* b, E* y, int T, int H, float eps) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* rows = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = blockIdx.x, ld = H + kRowPad;
-    const int nch = H >> 2;
-    block_to_lds(x, rb, H, rows, tid);
-    __syncthreads();
-    for (int i = 0; i < 8; ++i) {
-        const int row = wave * 8 + i, t = rb * 32 + row;
-        if (t >= T) continue;     // (rows past T keep whatever the block held: nothing valid depends on them)
-        float* o = rows + row * ld;
-        f32x4 v[kMaxChunks];
+__device__ __forceinline__ void frag_load8(const E* x, size_t frag, int lane, float (&v)[8]) {
+    if constexpr (sizeof(E) == 2) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(x + frag * 512 + lane * 8);
 #pragma unroll
-        for (int j = 0; j < kMaxChunks; ++j) {
-            const int ch = lane + 64 * j;
-            v[j] = ch < nch ? *reinterpret_cast<const f32x4*>(o + 4 * ch) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        ln_store(v, lane, H, eps, g, b, o);
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    } else {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + frag * 512 + lane * 4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(x + frag * 512 + 256 + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = c[e]; }
     }
+}
+template <typename E>
+__device__ __forceinline__ void frag_store8(E* x, size_t frag, int lane, const float (&v)[8]) {
+    if constexpr (sizeof(E) == 2) {
+        f16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (_Float16)v[e];
+        *reinterpret_cast<f16x8*>(x + frag * 512 + lane * 8) = t;
+    } else {
+        *reinterpret_cast<f32x4*>(x + frag * 512 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(x + frag * 512 + 256 + lane * 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// y = LayerNorm(x) per token; x and y tiled (may be the same buffer).  One workgroup per row block, no row image:
+// wave w takes the 16-feature steps w, w + 4, ... — whole fragments, 1 KiB per load and store instruction — and keeps
+// its lanes' values in registers (H / 8 floats per lane); a token's sum is its two lanes' (shuffle) over the four
+// waves' (128 floats of LDS), taken twice: mean, then the centred second moment, as the row-major kernel does.
+// NK = steps per wave = ceil(H / 64).
+template <typename E, int NK>
+__global__ __launch_bounds__(256) void ln_tiled_kernel(const E* x, const float* g, const float* b, E* y, int T, int H, float eps) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int rb = blockIdx.x, nks = H >> 4;
+    const size_t f0 = (size_t)rb * nks;
+    float v[NK][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int ks = wave + 4 * i;
+        if (ks < nks) {
+            frag_load8(x, f0 + ks, lane, v[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (h == 0) red[0][wave][r] = s;
     __syncthreads();
-    lds_to_block(rows, y, rb, H, tid);
+    const float mean = ((red[0][0][r] + red[0][1][r]) + (red[0][2][r] + red[0][3][r])) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+        if (wave + 4 * i < nks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q = __builtin_fmaf(d, d, q);
+            }
+        }
+    q += __shfl_xor(q, 32, 64);
+    if (h == 0) red[1][wave][r] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[1][0][r] + red[1][1][r]) + (red[1][2][r] + red[1][3][r])) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int ks = wave + 4 * i;
+        if (ks < nks) {
+            const int f = 16 * ks + 8 * h;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + f), g1 = *reinterpret_cast<const f32x4*>(g + f + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + f), b1 = *reinterpret_cast<const f32x4*>(b + f + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = (v[i][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+            frag_store8(y, f0 + ks, lane, o);
+        }
+    }
 }
 
 // attention_mfma_kernel (bert_kernels.hip.h) over a tiled qkv [T][3H]: same products, same softmax, same order of
@@ -233,6 +290,137 @@ __global__ __launch_bounds__(64) void attention_tiled_kernel(const E* qkv, const
             for (int dt = 0; dt < DH / 32; ++dt) {
                 const float vf = Vs[key * DH + dt * 32 + r];
                 oT[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sT[i], oT[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {oT[dt][4 * g] * inv, oT[dt][4 * g + 1] * inv, oT[dt][4 * g + 2] * inv, oT[dt][4 * g + 3] * inv};
+                const int f = head * DH + dt * 32 + 8 * g + 4 * h;
+                if (first_only)
+                    *reinterpret_cast<f32x4*>(ctx_first + (size_t)s * H + f) = v;
+                else
+                    tiled_store4(ctx, (long long)t0 + qidx, f, H, v);
+            }
+    }
+}
+
+// ---- attention on the fp16 matrix cores (T16 only) --------------------------------------------------------------------
+// One wave per (sequence, head, 32 query rows), the lane is the query, as above; but both products are
+// v_mfma_f32_32x32x16_f16 — 4 (DH = 32) or 8 matrix instructions per 32-key tile where the fp32 form issues 32 or 64 —
+// and the fragment-ordered layout feeds them directly:
+//   Sᵀ[key][query] = K·Qᵀ     A = K fragment, B = Q fragment: both are 16 contiguous bytes per lane in memory
+//                              (token = lane & 31, features 16 st + 8 (lane >> 5) ..), loaded straight into registers
+//   softmax                    fp32, over the lane's 16 registers, its partner lane and the key tiles; 1/sqrt(dh) is
+//                              applied to the fp32 scores
+//   Oᵀ[dh][query] += Vᵀ·Pᵀ     B = the probabilities where they sit: registers 8 s .. 8 s + 7 of the score tile, rounded to
+//                              fp16, are the k-step-s fragment with element j of lane half h = key 16 s + 8 (j >> 2) + 4 h +
+//                              (j & 3) (cdna_hip_programming.md §3, "an accumulator tile as the next MFMA's operand");
+//                              A = Vᵀ in that same key order, read from a row-major [key][dh] LDS tile with the hardware
+//                              transpose ds_read_b64_tr_b16 (T10): lane 4 q + p of a 16-lane group addresses key row q,
+//                              columns 4 p .. 4 p + 3, and receives its own column of the four rows.
+// V rows are 64 bytes apart for DH = 32 and 192 for DH = 64: a 32-lane half then reads 4 rows x 64 bytes from 64 distinct
+// banks.  EXEC is all ones at every transposed read (the only early exit is wave-uniform).
+typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+template <int DH>
+__global__ __launch_bounds__(64) void attention_t16_kernel(const _Float16* qkv, const int* cu, _Float16* ctx, float* ctx_first,
+                                                           int H, int heads, float scale, int first_only) {
+    using T = Tiled<_Float16>;
+    constexpr int VLD = DH == 32 ? 32 : 96;   // halves per V row in LDS
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[32 * VLD];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int s = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int t0 = cu[s], L = cu[s + 1] - t0;
+    if (qb * 32 >= L) return;
+    const int qidx = qb * 32 + r;
+    const bool qvalid = first_only ? qidx == 0 : qidx < L;
+    const int F = 3 * H;
+
+    f16x8 qf[DH / 16];
+    {
+        const long long qm = t0 + (qidx < L ? qidx : L - 1);
+#pragma unroll
+        for (int st = 0; st < DH / 16; ++st)
+            qf[st] = *reinterpret_cast<const f16x8*>(qkv + T::idx(qm, head * DH + 16 * st + 8 * h, F));
+    }
+    f32x16 oT[DH / 32];
+#pragma unroll
+    for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oT[dt][i] = 0.f;
+    float mx = -__builtin_inff(), den = 0.f;
+    // transposed read: this lane addresses row (lane & 15) >> 2 of a 4-key block, columns 16 ((lane >> 4) & 1) + 4 (lane & 3)
+    const int tr_off = ((lane & 15) >> 2) * VLD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    const int n_kt = (L + 31) / 32;
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * 32, nk = min(32, L - k0);
+        __syncthreads();   // the previous tile's reads of Vs are done
+        for (int idx = lane; idx < 32 * (DH / 8); idx += 64) {
+            const int j = idx & 31, c8 = (idx >> 5) * 8;
+            f16x8 vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] = (_Float16)0.f;
+            if (j < nk) vv = *reinterpret_cast<const f16x8*>(qkv + T::idx((long long)t0 + k0 + j, 2 * H + head * DH + c8, F));
+            *reinterpret_cast<f16x8*>(&Vs[j * VLD + c8]) = vv;
+        }
+        f16x8 kf[DH / 16];
+        {
+            const long long km = (long long)t0 + k0 + (r < nk ? r : nk - 1);   // keys past the sequence: masked below
+#pragma unroll
+            for (int st = 0; st < DH / 16; ++st)
+                kf[st] = *reinterpret_cast<const f16x8*>(qkv + T::idx(km, H + head * DH + 16 * st + 8 * h, F));
+        }
+        __syncthreads();
+
+        f32x16 sT;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sT[i] = 0.f;
+#pragma unroll
+        for (int st = 0; st < DH / 16; ++st) sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st], qf[st], sT, 0, 0, 0);
+        float tmax = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+            sT[i] = key < nk ? sT[i] * scale : -__builtin_inff();
+            tmax = fmaxf(tmax, sT[i]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mx, tmax);
+        const float alpha = expf(mx - mnew);
+        float psum = 0.f;
+        f16x8 pfr[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const _Float16 ph = (_Float16)expf(sT[i] - mnew);   // the denominator sums what the product will use
+            pfr[i >> 3][i & 7] = ph;
+            psum += (float)ph;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        den = den * alpha + psum;
+        mx = mnew;
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oT[dt][i] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const f16x8 pf = pfr[s2];
+#pragma unroll
+            for (int dt = 0; dt < DH / 32; ++dt) {
+                const _Float16* base = Vs + (16 * s2 + 4 * h) * VLD + dt * 32 + tr_off;
+                const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4_raw*)(base));
+                const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                    (__attribute__((address_space(3))) fp16x4_raw*)(base + 8 * VLD));
+                const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+                const f16x8 vf = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oT[dt], 0, 0, 0);
             }
         }
     }

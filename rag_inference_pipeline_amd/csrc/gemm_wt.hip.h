@@ -36,8 +36,9 @@ namespace ragb {
 // (embedding, attention, LayerNorm, pooling: bert_tiled.hip.h) uses the layout; M is padded to a multiple of 32 rows
 // in the buffers, and rows past M hold unspecified values that no valid row ever depends on.
 //
-// AK = 1 (T16): W one fp16 plane; fp32 accumulation, bias and activation on the fp32 sum, then fp16; the residual is
-//   added in fp16 (`dense(x) + input_tensor` of a .half() model, reference reranker.py:91-93).
+// AK = 1 (T16): W one fp16 plane; fp32 accumulation; bias, activation and the residual join the fp32 sum, which is
+//   rounded to fp16 once (a .half() model — reference reranker.py:91-93 — rounds `dense(x)` and the residual sum
+//   separately: this is the same arithmetic with one rounding fewer).
 // AK = 0 (T32): every fp32 operand as two fp16 planes, split in the wave's own registers — the arithmetic of
 //   gemm_nt_wl_kernel<2> term for term, so the results are bit-identical to it; range flag as there.
 // GELU for the fp16 path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, one rcp and one exp; erff costs ~3x as
@@ -230,9 +231,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_nt_wt_kernel(const GemmWtPa
             for (int e = 0; e < 4; ++e) v[e] = (AK == 1 && p.act == ACT_GELU_ERF) ? gelu_erf_fast(v[e]) : apply_act(v[e], p.act);
             const size_t step = (size_t)((n0 >> 4) + 2 * b + (g >> 1));
             if constexpr (AK == 1) {
-                f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 const size_t in_frag = (size_t)(32 * (g & 1) + r) * 8 + 4 * h;
-                if (p.R) hv += *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(p.R) + (r_rb + step) * 512 + in_frag);
+                if (p.R) {   // the residual joins the fp32 sum: one rounding to fp16, not two
+                    const f16x4 rv = *reinterpret_cast<const f16x4*>(static_cast<const _Float16*>(p.R) + (r_rb + step) * 512 + in_frag);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                }
+                const f16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 if ((ABL & 2) && hv[0] != (_Float16)123.25f) continue;   // (keeps the values live)
                 *reinterpret_cast<f16x4*>(static_cast<_Float16*>(p.C) + (c_rb + step) * 512 + in_frag) = hv;
             } else {

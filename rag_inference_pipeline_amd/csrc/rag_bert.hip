@@ -37,6 +37,7 @@ struct rag_bert {
     int n_cus = 256;
     bool valu_attention = false;  // RAG_AMD_VALU_ATTENTION=1: the VALU attention kernel (A/B checks)
     bool row_major_only = false;  // RAG_AMD_ROW_MAJOR=1: RAG_GEMM_F16 keeps fp32 row-major activations (A/B checks)
+    bool tiled_attention_f32 = false;  // RAG_AMD_TILED_ATTENTION_F32=1: fp32-MFMA attention on the tiled path (A/B checks)
     std::vector<const float*> w;
     // Fragment-order images of the four GEMM weights of every layer, owned here (gemm_wl.hip.h):
     //   wx2  RAG_GEMM_F32: two fp16 planes (hi, scaled lo) — the default big-batch path
@@ -403,9 +404,13 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     half_t* ffnh = reinterpret_cast<half_t*>(h->ffn);
     const int nrb = (T + 31) / 32;
     const int row_lds = 32 * (H + ragb::kRowPad) * (int)sizeof(float);
+    auto ln_tiled = [&](const half_t* src, const float* g, const float* b, half_t* dst) {   // steps per wave: H / 64
+        if (H <= 384) hipLaunchKernelGGL((ln_tiled_kernel<half_t, 6>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
+        else if (H <= 768) hipLaunchKernelGGL((ln_tiled_kernel<half_t, 12>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
+        else hipLaunchKernelGGL((ln_tiled_kernel<half_t, 16>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
+    };
     if (tiled) {
         if ((rc = ensure_lds(reinterpret_cast<const void*>(&embed_ln_tiled_kernel<half_t>), row_lds))) return rc;
-        if ((rc = ensure_lds(reinterpret_cast<const void*>(&ln_tiled_kernel<half_t>), row_lds))) return rc;
         hipLaunchKernelGGL(embed_ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, ep, xh);
     } else {
         embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
@@ -429,10 +434,16 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             if (last_first_only) {
                 // first tokens only: attention writes row-major fp32 rows, and the rest of the layer is the row-major tail
                 const dim3 fgrid(1, heads, nseq);
-                if (dh == 32)
-                    attention_tiled_kernel<32, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
-                else
-                    attention_tiled_kernel<64, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                if (h->tiled_attention_f32) {
+                    if (dh == 32)
+                        attention_tiled_kernel<32, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                    else
+                        attention_tiled_kernel<64, half_t><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                } else if (dh == 32) {
+                    attention_t16_kernel<32><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                } else {
+                    attention_t16_kernel<64><<<fgrid, dim3(64), 0, st>>>(qkvh, cu, nullptr, h->ctx, H, heads, scale, 1);
+                }
                 RAGC_HIP_TRY(hipGetLastError());
                 const int total = nseq * H;
                 gather_rows_tiled_kernel<half_t><<<dim3((total + 255) / 256), dim3(256), 0, st>>>(xh, cu, h->pooled, nseq, H);
@@ -446,21 +457,27 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 compact = true;
                 break;
             }
-            if (dh == 32)
-                attention_tiled_kernel<32, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
-            else
-                attention_tiled_kernel<64, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            if (h->tiled_attention_f32) {
+                if (dh == 32)
+                    attention_tiled_kernel<32, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+                else
+                    attention_tiled_kernel<64, half_t><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            } else if (dh == 32) {
+                attention_t16_kernel<32><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            } else {
+                attention_t16_kernel<64><<<mgrid, dim3(64), 0, st>>>(qkvh, cu, ctxh, nullptr, H, heads, scale, 0);
+            }
             RAGC_HIP_TRY(hipGetLastError());
             // attention output projection + bias + residual (fp16, in the epilogue), LayerNorm back into x
             rc = launch_gemm_t16(ctxh, H, h->wxf[at + 1], lw[3], xh, H, parth, H, T, H, H, ACT_NONE, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, parth, lw[4], lw[5], xh, T, H, c.ln_eps);
+            ln_tiled(parth, lw[4], lw[5], xh);
             RAGC_HIP_TRY(hipGetLastError());
             rc = launch_gemm_t16(xh, H, h->wxf[at + 2], lw[7], nullptr, 0, ffnh, I, T, I, H, act, st);
             if (rc) return rc;
             rc = launch_gemm_t16(ffnh, I, h->wxf[at + 3], lw[9], xh, H, parth, H, T, H, I, ACT_NONE, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, parth, lw[10], lw[11], xh, T, H, c.ln_eps);
+            ln_tiled(parth, lw[10], lw[11], xh);
             RAGC_HIP_TRY(hipGetLastError());
             continue;
         }
@@ -655,6 +672,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     h->valu_attention = va && *va == '1';
     const char* rm = getenv("RAG_AMD_ROW_MAJOR");
     h->row_major_only = rm && *rm == '1';
+    const char* ta = getenv("RAG_AMD_TILED_ATTENTION_F32");
+    h->tiled_attention_f32 = ta && *ta == '1';
     if (hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
         rag_bert_destroy(h);
         return ragc_fail(RAG_ERR_OOM, "allocation of the range flag failed");

@@ -183,12 +183,19 @@ def test_fp16_mode_big_batches_run_on_fragment_ordered_fp16_activations(gpu_requ
         monkeypatch.setenv("RAG_AMD_ROW_MAJOR", "1")
         rowm = BertModel(cfg, w)
         monkeypatch.delenv("RAG_AMD_ROW_MAJOR")
+        monkeypatch.setenv("RAG_AMD_TILED_ATTENTION_F32", "1")     # same layout, attention products on the fp32 MFMA
+        attn32 = BertModel(cfg, w)
+        monkeypatch.delenv("RAG_AMD_TILED_ATTENTION_F32")
         want_h = np.concatenate(obert.hidden_states(cfg, w, seqs, types))
         got_h, ref_h = tiled.hidden_states(seqs, types), rowm.hidden_states(seqs, types)
         scale = max(1.0, np.abs(want_h).max())
         assert np.abs(got_h - want_h).max() < 3e-2 * scale, np.abs(got_h - want_h).max()
         assert np.abs(got_h - ref_h).max() < 3e-2 * scale
         assert np.abs(got_h - ref_h).max() > 0          # and it really is another data path
+        a32_h = attn32.hidden_states(seqs, types)
+        assert np.abs(a32_h - want_h).max() < 3e-2 * scale
+        assert 0 < np.abs(got_h - a32_h).max() < 2e-2 * scale   # fp16-MFMA attention: P rounded to fp16, nothing else
+        attn32.close()
         for normalize in (True, False):
             want_e = obert.embed(cfg, w, seqs, types, normalize=normalize)
             got_e = tiled.embed(seqs, types, normalize=normalize)
