@@ -266,8 +266,12 @@ typedef struct rag_bert_config {
  *   never depend on the range, only the time does (rag_bert_range_events counts such passes).  A checkpoint with a
  *   GEMM weight outside fp16's range uses the three-plane path throughout.  The library builds the split weight
  *   images at rag_bert_create (+1x the GEMM weights' memory).
- * RAG_GEMM_F16: big-batch GEMMs take fp16 inputs (fp32 accumulate) — the precision the reference runs its reranker
- *   at on a GPU (reranker.py:91-93); the library builds the fp16 weight image itself.
+ * RAG_GEMM_F16: the precision the reference runs its reranker at on a GPU (reranker.py:91-93, model.half()).  Above
+ *   1024 tokens the whole pass keeps its activations in fp16, stored in MFMA-fragment order (csrc/gemm_wt.hip.h): GEMMs
+ *   and attention on the fp16 matrix cores with fp32 accumulation, softmax and LayerNorm statistics in fp32, bias /
+ *   activation / residual joined to the fp32 sums before the one rounding to fp16.  Outputs stay fp32 in the caller's
+ *   layout.  The library builds the fp16 weight image itself.  Batches of 1024 tokens or fewer run as in
+ *   RAG_GEMM_F32_STRICT.
  * RAG_GEMM_F32_STRICT: every GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32 chains). */
 #define RAG_GEMM_F32 0
 #define RAG_GEMM_F16 1

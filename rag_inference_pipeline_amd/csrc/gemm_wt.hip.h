@@ -104,7 +104,8 @@ struct WtGeom {
 };
 
 // ABL (experiment builds, scripts/exp/gemm_wh_bench.hip): 1 = every tile reads row blocks 0..NW-1 of A (always cache
-// resident), 2 = no output stores, 3 = both.  The product instantiates ABL = 0 only.
+// resident), 2 = no output stores, 4 = one W fragment read from LDS per K-step instead of NB (wrong values, same MFMAs and
+// DMA traffic).  The product instantiates ABL = 0 only.
 template <int AK, int NW, int NB, int KS, int NS, int OCC, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void gemm_nt_wt_kernel(const GemmWtParams p) {
     using Geo = WtGeom<AK, NW, NB, KS, NS>;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void gemm_nt_wt_kernel(const GemmWtPa
                 const f16x8 af = *reinterpret_cast<const f16x8*>(abase + ks * 1024);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const f16x8 wf = *reinterpret_cast<const f16x8*>(wbase + (b * KS + ks) * 1024);
+                    const f16x8 wf = *reinterpret_cast<const f16x8*>(wbase + (((ABL & 4) ? 0 : b) * KS + ks) * 1024);   // ABL 4: one W read per step
                     acc[b] = RAGB_WL_MFMA_F16(wf, af, acc[b]);
                 }
             } else {

@@ -91,7 +91,8 @@ def run(name, cfg, lens, out_kind, reps=10, cpu_sample=0, threads=16, gemm_dtype
            "frac_of_mode_mfma_peak": gf / ms / 1e9 / mode_peak(gemm_dtype, T)[0], "sequences_per_s": nseq / ms * 1e3,
            "dtype": {"f32": "f32 (big-batch GEMMs: two fp16 planes per operand, 3 products, on the fp16 matrix cores)",
                      "f32_strict": "f32 on the fp32 MFMA throughout",
-                     "f16": "f16 GEMM inputs, f32 accumulate / softmax / LayerNorm"}[gemm_dtype]}
+                     "f16": "fp16 activations in MFMA-fragment order above 1024 tokens (GEMMs and attention on the fp16 matrix cores), "
+                            "f32 accumulation, softmax and LayerNorm statistics"}[gemm_dtype]}
     print(f"{name}: nseq={nseq} tokens={T} maxlen={L}: {ms:.3f} ms/batch  GEMM {gf/1e9:.1f} GFLOP -> {gf/ms/1e9:.1f} TF/s "
           f"(attn {res['attention_gflop']:.2f} GFLOP)  {nseq/ms*1e3:.0f} seq/s", flush=True)
     model.close()
