@@ -34,8 +34,13 @@ from .schemas import Document, RerankedDocument, fast_constructor
 logger = logging.getLogger(__name__)
 
 _MAX_TOKENS_PER_PASS = 131072
-_PAIRS_PER_CHUNK = 640   # ~35 k tokens at the synthetic corpus' lengths: still the big-batch GEMM path
-_FIRST_CHUNK = 160       # the first chunk's tokenisation is the only one the GPU waits for: keep it short
+# Chunks: the first chunk's tokenisation is the only one the GPU waits for, and the GPU is the less efficient the
+# smaller a pass is (a 160-pair pass takes 2.0 ms, 640 pairs 1.5, 3200 pairs 5.8 in fp16 mode: the chip is not
+# covered below ~50 k tokens).  Round 3's native pair encoder needs 0.7 us per pair, so a quarter of the batch
+# (0.6 ms of tokenisation at 3200 pairs) goes first and the rest follows in one piece, tokenised under that pass.
+_PAIRS_PER_CHUNK = 4096
+_FIRST_FRACTION = 4
+_MIN_FIRST_CHUNK = 256
 _new_reranked = fast_constructor(RerankedDocument)
 
 
@@ -105,14 +110,15 @@ class Reranker:
         """Sigmoid scores of (query, document) pairs.  Pairs go through in chunks: while the GPU scores one
         chunk (the C call releases the GIL) a worker thread tokenises AND packs the next, so the calling
         thread does nothing between two GPU passes but hand over three arrays — host tokenisation and the
-        cross-encoder pass overlap instead of adding up.  The first chunk is short: its tokenisation is the
-        only one the GPU has to wait for."""
+        cross-encoder pass overlap instead of adding up.  The first chunk is a quarter of the batch: its
+        tokenisation is the only one the GPU has to wait for, and small passes use the GPU badly."""
         max_len = min(int(self.settings.truncate_length), self._max_len)
         with_types = self.model.cfg.type_vocab > 1
         n = len(docs)
         bounds, lo = [], 0
         while lo < n:
-            hi = min(lo + (_FIRST_CHUNK if lo == 0 and n > _PAIRS_PER_CHUNK else _PAIRS_PER_CHUNK), n)
+            first = max(_MIN_FIRST_CHUNK, n // _FIRST_FRACTION)
+            hi = min(lo + (first if lo == 0 and n >= 2 * _MIN_FIRST_CHUNK else _PAIRS_PER_CHUNK), n)
             bounds.append((lo, hi))
             lo = hi
 

@@ -327,33 +327,40 @@ __global__ __launch_bounds__(64) void attention_tiled_kernel(const E* qkv, const
 // banks.  EXEC is all ones at every transposed read (the only early exit is wave-uniform).
 typedef __fp16 fp16x4_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-template <int DH>
+// QB query blocks per wave (blockIdx.x covers 32 QB queries): the K fragments and the V tile of a key tile are loaded once
+// and used by every one of them.  The product runs QB = 1: FETCH_SIZE shows each sequence's K and V re-read per 32 queries
+// (0.84 GB per layer where qkv is 0.41) at 4.9 TB/s, yet QB = 2 — half those reads — measured 5 % SLOWER on both models
+// (8.2 vs 7.8 ms, 44.2 vs 42.7 per 3200 pairs): the re-reads come from the Infinity Cache, and half as many waves with
+// twice the serial work hide less latency.
+template <int DH, int QB>
 __global__ __launch_bounds__(64) void attention_t16_kernel(const _Float16* qkv, const int* cu, _Float16* ctx, float* ctx_first,
                                                            int H, int heads, float scale, int first_only) {
     using T = Tiled<_Float16>;
     constexpr int VLD = DH == 32 ? 32 : 96;   // halves per V row in LDS
     __shared__ __attribute__((aligned(16))) _Float16 Vs[32 * VLD];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int s = blockIdx.z, head = blockIdx.y, qb = blockIdx.x;
+    const int s = blockIdx.z, head = blockIdx.y, qb0 = blockIdx.x * QB;
     const int t0 = cu[s], L = cu[s + 1] - t0;
-    if (qb * 32 >= L) return;
-    const int qidx = qb * 32 + r;
-    const bool qvalid = first_only ? qidx == 0 : qidx < L;
+    if (qb0 * 32 >= L) return;
     const int F = 3 * H;
 
-    f16x8 qf[DH / 16];
-    {
+    f16x8 qf[QB][DH / 16];
+    f32x16 oT[QB][DH / 32];
+    float mx[QB], den[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qidx = (qb0 + b) * 32 + r;
         const long long qm = t0 + (qidx < L ? qidx : L - 1);
 #pragma unroll
         for (int st = 0; st < DH / 16; ++st)
-            qf[st] = *reinterpret_cast<const f16x8*>(qkv + T::idx(qm, head * DH + 16 * st + 8 * h, F));
+            qf[b][st] = *reinterpret_cast<const f16x8*>(qkv + T::idx(qm, head * DH + 16 * st + 8 * h, F));
+#pragma unroll
+        for (int dt = 0; dt < DH / 32; ++dt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oT[b][dt][i] = 0.f;
+        mx[b] = -__builtin_inff();
+        den[b] = 0.f;
     }
-    f32x16 oT[DH / 32];
-#pragma unroll
-    for (int dt = 0; dt < DH / 32; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oT[dt][i] = 0.f;
-    float mx = -__builtin_inff(), den = 0.f;
     // transposed read: this lane addresses row (lane & 15) >> 2 of a 4-key block, columns 16 ((lane >> 4) & 1) + 4 (lane & 3)
     const int tr_off = ((lane & 15) >> 2) * VLD + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
@@ -378,59 +385,67 @@ __global__ __launch_bounds__(64) void attention_t16_kernel(const _Float16* qkv, 
         }
         __syncthreads();
 
-        f32x16 sT;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sT[i] = 0.f;
+        for (int b = 0; b < QB; ++b) {
+            if (b > 0 && (qb0 + b) * 32 >= L) break;   // (wave-uniform: EXEC stays all ones at the transposed reads)
+            f32x16 sT;
 #pragma unroll
-        for (int st = 0; st < DH / 16; ++st) sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st], qf[st], sT, 0, 0, 0);
-        float tmax = -__builtin_inff();
+            for (int i = 0; i < 16; ++i) sT[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-            sT[i] = key < nk ? sT[i] * scale : -__builtin_inff();
-            tmax = fmaxf(tmax, sT[i]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mx, tmax);
-        const float alpha = expf(mx - mnew);
-        float psum = 0.f;
-        f16x8 pfr[2];
+            for (int st = 0; st < DH / 16; ++st) sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[st], qf[b][st], sT, 0, 0, 0);
+            float tmax = -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const _Float16 ph = (_Float16)expf(sT[i] - mnew);   // the denominator sums what the product will use
-            pfr[i >> 3][i & 7] = ph;
-            psum += (float)ph;
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        den = den * alpha + psum;
-        mx = mnew;
+            for (int i = 0; i < 16; ++i) {
+                const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+                sT[i] = key < nk ? sT[i] * scale : -__builtin_inff();
+                tmax = fmaxf(tmax, sT[i]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mx[b], tmax);
+            const float alpha = expf(mx[b] - mnew);
+            float psum = 0.f;
+            f16x8 pfr[2];
 #pragma unroll
-        for (int dt = 0; dt < DH / 32; ++dt)
+            for (int i = 0; i < 16; ++i) {
+                const _Float16 ph = (_Float16)expf(sT[i] - mnew);   // the denominator sums what the product will use
+                pfr[i >> 3][i & 7] = ph;
+                psum += (float)ph;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            den[b] = den[b] * alpha + psum;
+            mx[b] = mnew;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) oT[dt][i] *= alpha;
+            for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const f16x8 pf = pfr[s2];
+                for (int i = 0; i < 16; ++i) oT[b][dt][i] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < DH / 32; ++dt) {
-                const _Float16* base = Vs + (16 * s2 + 4 * h) * VLD + dt * 32 + tr_off;
-                const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) fp16x4_raw*)(base));
-                const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) fp16x4_raw*)(base + 8 * VLD));
-                const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
-                const f16x8 vf = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
-                oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oT[dt], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const f16x8 pf = pfr[s2];
+#pragma unroll
+                for (int dt = 0; dt < DH / 32; ++dt) {
+                    const _Float16* base = Vs + (16 * s2 + 4 * h) * VLD + dt * 32 + tr_off;
+                    const fp16x4_raw lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(base));
+                    const fp16x4_raw hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_raw*)(base + 8 * VLD));
+                    const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+                    const f16x8 vf = {l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                    oT[b][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oT[b][dt], 0, 0, 0);
+                }
             }
         }
     }
-    if (qvalid) {
-        const float inv = 1.0f / den;
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qidx = (qb0 + b) * 32 + r;
+        const bool qvalid = first_only ? qidx == 0 : qidx < L;
+        if (!qvalid) continue;
+        const float inv = 1.0f / den[b];
 #pragma unroll
         for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = {oT[dt][4 * g] * inv, oT[dt][4 * g + 1] * inv, oT[dt][4 * g + 2] * inv, oT[dt][4 * g + 3] * inv};
+                const f32x4 v = {oT[b][dt][4 * g] * inv, oT[b][dt][4 * g + 1] * inv, oT[b][dt][4 * g + 2] * inv, oT[b][dt][4 * g + 3] * inv};
                 const int f = head * DH + dt * 32 + 8 * g + 4 * h;
                 if (first_only)
                     *reinterpret_cast<f32x4*>(ctx_first + (size_t)s * H + f) = v;
