@@ -48,6 +48,8 @@ def parse_args() -> argparse.Namespace:
     ap.add_argument("--latency-steps", type=int, default=20)
     ap.add_argument("--no-encoder-leg", action="store_true",
                     help="skip the extra text->ids leg (query encoder in front of the scan)")
+    ap.add_argument("--no-rerank-leg", action="store_true",
+                    help="skip the extra cross-encoder stage leg (32 x 100 synthetic (query, document) pairs)")
     ap.add_argument("--no-two-stage-leg", action="store_true",
                     help="skip the extra leg through the two-stage exact search (fp16 screen + fp32 second stage)")
     return ap.parse_args()
@@ -372,6 +374,50 @@ def main() -> None:
                    "encoder": "bge-base-en-v1.5 architecture (12x768), seeded random weights, CLS pooling + L2 norm, "
                               "two-plane fp16 GEMMs (fp32 accuracy); token ids resident in HBM"}
 
+    # Extra leg (never `value`, one GPU only): the stage BASELINE configs[2] puts behind the scan — the cross-encoder
+    # over 32 x 100 (query, document) pairs (reference reranker.py:237-272), ms-marco-MiniLM-L-6 architecture with
+    # seeded random weights, token ids resident in HBM; in the default fp32-accurate mode and in the fp16 mode the
+    # reference itself uses on a GPU (reranker.py:91-93).
+    rerank_leg = None
+    if not args.no_rerank_leg and world == 1:
+        from rag_inference_pipeline_amd import _native
+        from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
+
+        rng = np.random.default_rng(99)
+        plens = rng.integers(36, 76, size=B * 100)
+        pseqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in plens]
+        pids, ptypes, pcu = pack_sequences(pseqs, [[0] * 10 + [1] * (len(q) - 10) for q in pseqs])
+        pids_t, ptypes_t, pcu_t = (torch.from_numpy(a).cuda() for a in (pids, ptypes, pcu))
+        pout = torch.empty((len(pseqs), 1), dtype=torch.float32, device="cuda")
+        rerank_leg = {"pairs": len(pseqs), "tokens": int(pcu[-1]),
+                      "model": "cross-encoder/ms-marco-MiniLM-L-6-v2 architecture (6 x 384), seeded random weights; "
+                               "token ids resident in HBM, sigmoid scores left in HBM"}
+        for mode, key in (("f32", "default_fp32_accurate"), ("f16", "fp16_mode")):
+            rcfg = BertConfig.ms_marco_minilm_l6()
+            rcfg.gemm_dtype = mode
+            rmodel = BertModel(rcfg, random_weights(rcfg, 0), device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+
+            def rpass():
+                rmodel.forward_device(pids_t.data_ptr(), ptypes_t.data_ptr(), pcu_t.data_ptr(), len(pseqs), int(pcu[-1]),
+                                      int(plens.max()), _native.BERT_OUT_PROBS, False, pout.data_ptr(), st)
+            for _ in range(3):
+                rpass()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                rpass()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            rerank_leg[key] = {"ms_per_batch": ms, "pairs_per_s": len(pseqs) / ms * 1e3,
+                               "score_checksum": float(pout.sum().item())}
+            rmodel.close()
+        rerank_leg["note"] = ("default: GEMMs on the fp16 matrix cores with every fp32 operand as two fp16 planes (fp32 accuracy); "
+                              "fp16_mode (RAG_AMD_RERANKER_DTYPE=f16): fp16 activations stored in MFMA-fragment order, GEMMs and "
+                              "attention on the fp16 matrix cores, fp32 accumulation and statistics")
+
     # Extra leg (never `value`): the same step through the two-stage exact search — fp16 screening scan
     # of a scaled copy of the corpus, canonical fp32 re-scoring of the band, per-query certificate,
     # device-side fp32 fallback (include/rag_amd.h rag_index_set_screening).  Same ids, same score bits.
@@ -526,6 +572,8 @@ def main() -> None:
             out["with_query_encoder"] = enc_leg
         if two_leg is not None:
             out["two_stage_exact"] = two_leg
+        if rerank_leg is not None:
+            out["rerank_stage"] = rerank_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
