@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../rag_inference_pipeline_amd/csrc/bert_kernels.hip.h"
 #include "gemm_wh_rowmajor.hip.h"
+#include "gemm_wt16.hip.h"
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
 
 static std::vector<float> rnd(size_t n, unsigned seed, bool to_f16) {
@@ -68,6 +69,16 @@ static void launch_wt(const ragb::GemmWtParams& g) {
     hipLaunchKernelGGL(fn, grid, dim3(Geo::THREADS), Geo::LDS, 0, g);
 }
 
+template <int KS, int NS>
+static void launch_wt16(const ragb::GemmWtParams& g) {
+    using Geo = ragb::Wt16Geom<KS, NS>;
+    static bool once = false;
+    auto fn = &ragb::gemm_nt_wt16_kernel<KS, NS>;
+    if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS)); once = true; }
+    dim3 grid(ragb::xcd_grid(g.M, g.N, Geo::TM, Geo::TN), 1, 1);
+    hipLaunchKernelGGL(fn, grid, dim3(Geo::THREADS), Geo::LDS, 0, g);
+}
+
 static int g_mode = 3;   // 1: fp16 (T16) variants, 2: two-plane fp32 (T32) variants, 4: row-major 256-row kernels, 8: ablations
 
 static void run(int M, int N, int K, int act, bool res, const char* name) {
@@ -86,7 +97,7 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
     printf("%-22s M=%6d N=%5d K=%5d\n", name, M, N, K);
     std::vector<float> c0(mn);
 
-    if (g_mode & (1 | 4 | 8 | 32)) {
+    if (g_mode & (1 | 4 | 8 | 32 | 512)) {
         // ---- fp16 activations against the fp32-activation fp16-input kernel (no residual there: it is added here in fp16)
         std::vector<_Float16> hA16(mk), hR16(mn);
         for (size_t i = 0; i < mk; ++i) hA16[i] = (_Float16)hA[i];
@@ -144,6 +155,11 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
             checkt("T16 wt<NW=4,NB=4,KS=2,NS=3> 128x128 x3", time_ms([&] { launch_wt<1, 4, 4, 2, 3, 3>(gt); }));
             if (N % 256 == 0) checkt("T16 wt<NW=4,NB=8,KS=2,NS=3> 128x256 x2", time_ms([&] { launch_wt<1, 4, 8, 2, 3, 2>(gt); }));
         }
+        if ((g_mode & 512) && N % 256 == 0) {
+            checkt("T16 wt<8,4,1,4,3> 256x128 x3 (product)", time_ms([&] { launch_wt<1, 8, 4, 1, 4, 3>(gt); }));
+            checkt("T16 wt16<KS=2,NS=3> 256x256, 16 waves", time_ms([&] { launch_wt16<2, 3>(gt); }));
+            checkt("T16 wt16<KS=2,NS=4> 256x256, 16 waves", time_ms([&] { launch_wt16<2, 4>(gt); }));
+        }
         if (g_mode & 32) checkt("T16 wt<NW=8,NB=4,KS=1,NS=4> 256x128 x3", time_ms([&] { launch_wt<1, 8, 4, 1, 4, 3>(gt); }));
         if (g_mode & 8) {
             checkt("  ablation: A always from slab 0", time_ms([&] { launch_wt<1, 8, 4, 2, 3, 2, 1>(gt); }));
@@ -156,6 +172,11 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
         (void)hipFree(dA); (void)hipFree(dR); (void)hipFree(dC);
     }
 
+    if (g_mode & 256) {
+        ragb::GemmWlParams w2{A, W2, b, res ? R : nullptr, C0, M, N, K, K, N, N, act, nullptr};
+        const float t2 = time_ms([&] { launch_wl<2, 1, 3>(w2); });
+        printf("    row-major two-plane wl<2;1,3> 128x128 x2       %7.3f ms %6.1f TF\n", t2, flop / t2 / 1e9);
+    }
     if (g_mode & 2) {
         // ---- two fp16 planes, fp32 in memory: must equal gemm_nt_wl_kernel<2> bit for bit
         ragb::GemmWlParams w2{A, W2, b, res ? R : nullptr, C0, M, N, K, K, N, N, act, nullptr};
@@ -196,6 +217,20 @@ static void run(int M, int N, int K, int act, bool res, const char* name) {
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 178405;
     g_mode = argc > 2 ? atoi(argv[2]) : 3;
+    if (g_mode == 512) {  // the 16-wave 256 x 256 experiment on the shapes whose N is a multiple of 256
+        run(4096 + 37, 512, 384, ragb::ACT_NONE, true, "small check");
+        run(M, 1536, 384, ragb::ACT_GELU_ERF, false, "ffn1 + gelu");
+        run(M, 2304, 768, ragb::ACT_NONE, false, "qkv (base)");
+        run(M, 768, 768, ragb::ACT_NONE, true, "attn out (base)");
+        run(M, 3072, 768, ragb::ACT_GELU_ERF, false, "ffn1 (base) + gelu");
+        run(M, 768, 3072, ragb::ACT_NONE, true, "ffn2 (base)");
+        return 0;
+    }
+    if (g_mode == 128) {  // counter runs: the default mode's two-plane kernel on one shape, nothing else
+        g_mode = 256;
+        run(M, 1152, 384, ragb::ACT_NONE, false, "qkv (MiniLM), two-plane counters");
+        return 0;
+    }
     if (g_mode == 16) {   // counter runs: the product's T16 kernel on one shape, nothing else
         g_mode = 32;
         run(M, 1152, 384, ragb::ACT_NONE, false, "qkv (MiniLM), counters");
