@@ -366,11 +366,74 @@ def main() -> None:
         model.set_background(True)    # kernels that fit beside the scan's resident workgroups (include/rag_amd.h)
         el_p = timed_loop(enc_pipe_step)
         model.set_background(False)
+        pipelined = {"value": B * args.steps / el_p, "unit": "queries/s", "ms_per_step": el_p / args.steps * 1e3,
+                     "how": "encoder of batch i on a side stream under the scan of batch i - 1, its small-batch GEMMs in the "
+                            "32-KiB-LDS form that fits beside the scan's resident workgroups (both on all CUs)"}
+        # The same pipeline with the chip PARTITIONED: the encoder's stream owns 32 CUs (one per shader engine), the scan's
+        # stream the other 224 — the scan is HBM-bound and loses 6 %, and the encoder's ~90 short dependent kernels no
+        # longer queue behind the scan's resident workgroups (include/rag_amd.h rag_stream_create_masked).  Shares that
+        # leave the shader engines unequal (16, 24, 40, 48 CUs) DOUBLE the scan's time: workgroups are dealt to engines by
+        # count, an engine with fewer CUs than workgroups runs two persistent workgroups in turn.
+        if sharded is None:
+            from rag_inference_pipeline_amd.flat_index import create_masked_stream, destroy_stream
+
+            total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            enc_cus = int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32"))   # one CU of every shader engine of every XCD
+            enc_raw = create_masked_stream(dev, 0, enc_cus)
+            scan_raw = create_masked_stream(dev, enc_cus, total_cus - enc_cus)
+            enc_st, scan_st = torch.cuda.ExternalStream(enc_raw), torch.cuda.ExternalStream(scan_raw)
+            part_n = [0]
+
+            def enc_part_step() -> None:
+                n = part_n[0]
+                part_n[0] += 1
+                Qe = Qe2[n % 3]
+                if n >= 3:
+                    enc_st.wait_event(ev_srch[n % 3])
+                model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                     _native.BERT_OUT_CLS, True, Qe.data_ptr(), enc_raw)
+                ev_enc[n % 3].record(enc_st)
+                scan_st.wait_event(ev_enc[n % 3])
+                index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw)
+                ev_srch[n % 3].record(scan_st)
+
+            model.set_cu_budget(enc_cus)
+            index.set_cu_budget(total_cus - enc_cus)
+
+            def alone(fn, st) -> float:   # ms per call of one side alone on its share of the chip
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for _ in range(10):
+                    fn()
+                e1.record(st)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 10
+
+            enc_alone = alone(lambda: model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                                           _native.BERT_OUT_CLS, True, Qe2[0].data_ptr(), enc_raw), enc_st)
+            scan_alone = alone(lambda: index.search_device(Qe2[0].data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw), scan_st)
+            el_q = timed_loop(enc_part_step)
+            torch.cuda.synchronize()
+            ids_part = out_i.cpu().numpy().copy()
+            model.set_cu_budget(0)
+            index.set_cu_budget(0)
+            enc_step()
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(ids_part, out_i.cpu().numpy()))
+            del enc_st, scan_st
+            destroy_stream(dev, enc_raw)
+            destroy_stream(dev, scan_raw)
+            pipelined = {"value": B * args.steps / el_q, "unit": "queries/s", "ms_per_step": el_q / args.steps * 1e3,
+                         "how": f"encoder of batch i on a stream that owns {enc_cus} CUs ({enc_cus // 8} per XCD), scan of batch i - 1 on "
+                                f"a stream that owns the other {total_cus - enc_cus} (rag_stream_create_masked, rag_*_set_cu_budget)",
+                         "encoder_cus": enc_cus, "encoder_alone_ms_on_its_cus": enc_alone, "scan_alone_ms_on_its_cus": scan_alone,
+                         "identical_to_sequential": same, "time_shared_cus": pipelined}
         enc_leg = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
                    "tokens_per_batch": int(cu_np[-1]),
-                   "pipelined": {"value": B * args.steps / el_p, "unit": "queries/s", "ms_per_step": el_p / args.steps * 1e3,
-                                 "how": "encoder of batch i on a side stream under the scan of batch i - 1, its small-batch GEMMs in the "
-                                        "32-KiB-LDS form that fits beside the scan's resident workgroups"},
+                   "pipelined": pipelined,
                    "encoder": "bge-base-en-v1.5 architecture (12x768), seeded random weights, CLS pooling + L2 norm, "
                               "two-plane fp16 GEMMs (fp32 accuracy); token ids resident in HBM"}
 

@@ -165,6 +165,22 @@ int rag_index_get_rows(rag_index* h, int64_t row0, int64_t n, float* out_rows_ho
 int rag_index_profile_enable(rag_index* h, int32_t on);
 int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* scan_launches, int32_t reset);
 
+/* A share of the chip for a stage (no counterpart in the reference, whose stages time-share one device):
+ * rag_stream_create_masked returns a hipStream_t whose kernels run only on the compute units with mask bits
+ * [first_cu, first_cu + n_cus) of hipExtStreamCreateWithCUMask's enumeration.  On MI355X that enumeration interleaves
+ * the 8 XCDs and, inside an XCD, its 4 shader engines — 32 consecutive bits are one CU of every engine of every XCD
+ * (scripts/exp/cumask_probe.hip).  Use multiples of 32: workgroups are dealt to the engines by count, so a share that
+ * leaves the engines unequal puts two workgroups of a one-per-CU grid on one CU (measured: the corpus scan on 240, 232,
+ * 216 or 208 CUs takes TWICE as long as on 224 or 256).  rag_index_set_cu_budget / rag_bert_set_cu_budget tell a handle how many CUs its
+ * launches may count on (grid of the persistent scan kernel, tile and split-K choices of the small GEMMs); 0 = the
+ * whole device (the default).  Use: the query encoder of batch i + 1 on 16 CUs beside the corpus scan of batch i on
+ * the other 240 — the scan is HBM-bound and loses nothing, the encoder no longer shares CUs with it (bench.py,
+ * with_query_encoder.pipelined).  Results do not depend on either setting. */
+int rag_stream_create_masked(int32_t device, int32_t first_cu, int32_t n_cus, void** stream_out);
+int rag_stream_destroy(int32_t device, void* stream);
+int rag_index_set_cu_budget(rag_index* h, int32_t n_cus);
+/* (rag_bert_set_cu_budget is declared with the rag_bert entry points below.) */
+
 /* Largest k the fused scan+select kernel supports for (d, nq) on this build; 0 if d unsupported. */
 int32_t rag_index_max_k(int32_t d, int32_t nq);
 
@@ -316,6 +332,9 @@ int rag_bert_forward_device(rag_bert* h, const int32_t* ids_dev, const int32_t* 
  * LDS resident on every CU for milliseconds, and only workgroups that fit beside it start before it ends.  Slower
  * when nothing else runs (a barrier per 16-deep K-step), same results.  (No counterpart in the reference.) */
 int rag_bert_set_background(rag_bert* h, int32_t on);
+
+/* CUs this model's launches may count on; 0 = the whole device (see rag_stream_create_masked). */
+int rag_bert_set_cu_budget(rag_bert* h, int32_t n_cus);
 
 /* Passes the host-pointer entry point has repeated on the three-plane path because an activation left fp16's range
  * (RAG_GEMM_F32, see above).  `pending` (may be NULL; synchronises the device when given): 1 when a pass of one of the

@@ -141,6 +141,10 @@ def _declare(lib: C.CDLL) -> None:
         "rag_bert_forward": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, f32p]),
         "rag_bert_range_events": (C.c_int, [vp, i64p, i32p]),
         "rag_bert_set_background": (C.c_int, [vp, C.c_int32]),
+        "rag_bert_set_cu_budget": (C.c_int, [vp, C.c_int32]),
+        "rag_index_set_cu_budget": (C.c_int, [vp, C.c_int32]),
+        "rag_stream_create_masked": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+        "rag_stream_destroy": (C.c_int, [C.c_int32, C.c_void_p]),
         "rag_bert_forward_to_device": (C.c_int, [vp, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, vp, vp,
                                                  C.POINTER(vp)]),
         "rag_bert_forward_device": (C.c_int, [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,

@@ -326,6 +326,11 @@ class BertModel:
         kernel such as the corpus scan (rag_bert_set_background)."""
         _native.check(self._lib.rag_bert_set_background(self._h, 1 if on else 0))
 
+    def set_cu_budget(self, n_cus: int = 0) -> None:
+        """How many compute units this model's launches may count on (0 = the whole device): for a caller that runs it
+        on a stream restricted to a share of the chip (rag_stream_create_masked)."""
+        _native.check(self._lib.rag_bert_set_cu_budget(self._h, int(n_cus)))
+
     def range_events(self, take_pending: bool = False) -> tuple[int, bool]:
         """(forward passes repeated on the three-plane bf16 path because an activation left fp16's range, whether an
         asynchronous pass has raised the flag since it was last taken) — rag_bert_range_events."""

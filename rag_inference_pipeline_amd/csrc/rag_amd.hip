@@ -972,6 +972,47 @@ extern "C" int rag_index_set_id_offset(rag_index* h, int64_t id_offset) {
     return RAG_OK;
 }
 
+extern "C" int rag_stream_create_masked(int32_t device, int32_t first_cu, int32_t n_cus, void** stream_out) {
+    if (!stream_out) return fail(RAG_ERR_INVALID_ARG, "stream_out is null");
+    *stream_out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RAG_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(RAG_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    hipDeviceProp_t prop;
+    RAGC_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int total = prop.multiProcessorCount;
+    if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total)
+        return fail(RAG_ERR_INVALID_ARG, "CU range [%d, %d) outside the device's %d", first_cu, first_cu + n_cus, total);
+    RagcDeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    for (int b = first_cu; b < first_cu + n_cus; ++b) mask[(size_t)b >> 5] |= 1u << (b & 31);
+    hipStream_t st = nullptr;
+    RAGC_HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream_out = (void*)st;
+    return RAG_OK;
+}
+
+extern "C" int rag_stream_destroy(int32_t device, void* stream) {
+    if (!stream) return RAG_OK;
+    RagcDeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    RAGC_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    RAGC_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return RAG_OK;
+}
+
+extern "C" int rag_index_set_cu_budget(rag_index* h, int32_t n_cus) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    hipDeviceProp_t prop;
+    RAGC_HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    if (n_cus < 0 || n_cus > prop.multiProcessorCount)
+        return fail(RAG_ERR_INVALID_ARG, "CU budget %d outside [0, %d]", n_cus, prop.multiProcessorCount);
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->n_cus = n_cus == 0 ? prop.multiProcessorCount : n_cus;
+    return RAG_OK;
+}
+
 extern "C" int rag_index_set_screening(rag_index* h, int32_t mode) {
     if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
     if (mode != RAG_SCREEN_OFF && mode != RAG_SCREEN_FP16) return fail(RAG_ERR_INVALID_ARG, "unknown screening mode %d", mode);

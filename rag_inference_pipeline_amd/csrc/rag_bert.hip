@@ -868,6 +868,17 @@ extern "C" int rag_bert_set_background(rag_bert* h, int32_t on) {
     return RAG_OK;
 }
 
+extern "C" int rag_bert_set_cu_budget(rag_bert* h, int32_t n_cus) {
+    if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
+    hipDeviceProp_t prop;
+    RAGC_HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+    if (n_cus < 0 || n_cus > prop.multiProcessorCount)
+        return ragc_fail(RAG_ERR_INVALID_ARG, "CU budget %d outside [0, %d]", n_cus, prop.multiProcessorCount);
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->n_cus = n_cus == 0 ? prop.multiProcessorCount : n_cus;
+    return RAG_OK;
+}
+
 extern "C" int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pending) {
     if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
     RagcDeviceGuard g(h->device);

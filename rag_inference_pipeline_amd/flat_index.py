@@ -138,6 +138,11 @@ class FlatIndex:
                                                        1 if reset else 0))
         return {"queries": int(q.value), "fallbacks": int(f.value), "max_err_ratio": float(r.value)}
 
+    def set_cu_budget(self, n_cus: int = 0) -> None:
+        """How many compute units a search may count on (the persistent scan kernel's grid); 0 = the whole device.
+        For searches enqueued on a stream restricted to a share of the chip (create_masked_stream)."""
+        _native.check(self._lib.rag_index_set_cu_budget(self._handle(), int(n_cus)))
+
     # -- profiling ------------------------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         _native.check(self._lib.rag_index_profile_enable(self._handle(), 1 if on else 0))
@@ -182,3 +187,16 @@ def merge_topk_packed_device(device: int, metric: int, n_shards: int, nq: int, k
     _native.check(_native.lib().rag_merge_topk_packed_device(
         int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(packed_ptr), int(shard_stride_bytes),
         int(scores_offset_bytes), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr), C.c_void_p(stream)))
+
+
+def create_masked_stream(device: int, first_cu: int, n_cus: int) -> int:
+    """A hipStream_t (as an integer) whose kernels run on the CUs [first_cu, first_cu + n_cus) of the CU-mask enumeration
+    (rag_stream_create_masked); wrap it with torch.cuda.ExternalStream to use it from torch.  destroy_stream releases it."""
+    lib = _native.lib()
+    st = C.c_void_p()
+    _native.check(lib.rag_stream_create_masked(int(device), int(first_cu), int(n_cus), C.byref(st)))
+    return int(st.value)
+
+
+def destroy_stream(device: int, stream: int) -> None:
+    _native.check(_native.lib().rag_stream_destroy(int(device), C.c_void_p(int(stream))))

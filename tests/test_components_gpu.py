@@ -357,3 +357,54 @@ def test_build_index_tool_embeds_documents_and_round_trips(gpu_required, tmp_pat
     with pytest.raises(ValueError, match="build id"):
         build_index(str(docs_dir), model, str(tmp_path / "x.f32"), rank=1, world=2)
     assert not list(tmp_path.glob("*.done"))
+
+
+def test_a_share_of_the_chip_for_each_stage_changes_no_result(gpu_required):
+    """rag_stream_create_masked + rag_*_set_cu_budget (include/rag_amd.h): the scan on 224 CUs and the encoder on 32
+    return exactly what they return on the whole device."""
+    import torch
+    from oracle import flat as oracle
+    from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
+    from rag_inference_pipeline_amd import _native
+    from rag_inference_pipeline_amd.flat_index import FlatIndex, create_masked_stream, destroy_stream
+
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    if total < 64:
+        pytest.skip("needs a device with at least 64 compute units")
+    d, nq, k = 384, 32, 10
+    idx = FlatIndex(d); idx.add_synthetic(300_000, 7)
+    Q = torch.from_numpy(oracle.synth_rows(99, 0, nq, d)).cuda()
+    s0 = torch.empty((nq, k), dtype=torch.float32, device="cuda"); i0 = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    s1, i1 = torch.empty_like(s0), torch.empty_like(i0)
+    idx.search_device(Q.data_ptr(), nq, k, s0.data_ptr(), i0.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    scan_st = create_masked_stream(0, 32, total - 32)
+    enc_st = create_masked_stream(0, 0, 32)
+    try:
+        idx.set_cu_budget(total - 32)
+        idx.search_device(Q.data_ptr(), nq, k, s1.data_ptr(), i1.data_ptr(), scan_st)
+        torch.cuda.synchronize()
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+        idx.set_cu_budget(0)
+
+        cfg = BertConfig.minilm_l6(); cfg.vocab_size = 2000; cfg.n_layers = 2
+        model = BertModel(cfg, random_weights(cfg, 3))
+        rng = np.random.default_rng(3)
+        seqs = [rng.integers(3, cfg.vocab_size, size=int(n)).tolist() for n in rng.integers(8, 21, size=32)]
+        ids, _, cu = pack_sequences(seqs)
+        ids_t, cu_t = torch.from_numpy(ids).cuda(), torch.from_numpy(cu).cuda()
+        e0 = torch.empty((32, cfg.hidden), dtype=torch.float32, device="cuda"); e1 = torch.empty_like(e0)
+        args = (ids_t.data_ptr(), 0, cu_t.data_ptr(), 32, int(cu[-1]), int(max(map(len, seqs))), _native.BERT_OUT_MEAN, True)
+        model.forward_device(*args, e0.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        model.set_cu_budget(32)
+        model.forward_device(*args, e1.data_ptr(), enc_st)
+        torch.cuda.synchronize()
+        # (the CU budget may change a split-K count, i.e. a summation order: equal to fp32 rounding, not bit for bit)
+        np.testing.assert_allclose(e1.cpu().numpy(), e0.cpu().numpy(), atol=2e-6)
+        model.close()
+    finally:
+        destroy_stream(0, scan_st); destroy_stream(0, enc_st)
+        idx.close()
+    with pytest.raises(RuntimeError):
+        create_masked_stream(0, total - 8, 16)      # outside the device
