@@ -374,11 +374,10 @@ def main() -> None:
         # longer queue behind the scan's resident workgroups (include/rag_amd.h rag_stream_create_masked).  Shares that
         # leave the shader engines unequal (16, 24, 40, 48 CUs) DOUBLE the scan's time: workgroups are dealt to engines by
         # count, an engine with fewer CUs than workgroups runs two persistent workgroups in turn.
-        if sharded is None:
+        def run_partitioned(enc_cus: int, time_shared: dict) -> dict:
             from rag_inference_pipeline_amd.flat_index import create_masked_stream, destroy_stream
 
             total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            enc_cus = int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32"))   # one CU of every shader engine of every XCD
             enc_raw = create_masked_stream(dev, 0, enc_cus)
             scan_raw = create_masked_stream(dev, enc_cus, total_cus - enc_cus)
             enc_st, scan_st = torch.cuda.ExternalStream(enc_raw), torch.cuda.ExternalStream(scan_raw)
@@ -426,11 +425,14 @@ def main() -> None:
             del enc_st, scan_st
             destroy_stream(dev, enc_raw)
             destroy_stream(dev, scan_raw)
-            pipelined = {"value": B * args.steps / el_q, "unit": "queries/s", "ms_per_step": el_q / args.steps * 1e3,
+            return {"value": B * args.steps / el_q, "unit": "queries/s", "ms_per_step": el_q / args.steps * 1e3,
                          "how": f"encoder of batch i on a stream that owns {enc_cus} CUs ({enc_cus // 8} per XCD), scan of batch i - 1 on "
                                 f"a stream that owns the other {total_cus - enc_cus} (rag_stream_create_masked, rag_*_set_cu_budget)",
                          "encoder_cus": enc_cus, "encoder_alone_ms_on_its_cus": enc_alone, "scan_alone_ms_on_its_cus": scan_alone,
-                         "identical_to_sequential": same, "time_shared_cus": pipelined}
+                         "identical_to_sequential": same, "time_shared_cus": time_shared}
+
+        if sharded is None:   # (32: one CU of every shader engine of every XCD)
+            pipelined = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32")), pipelined)
         enc_leg = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
                    "tokens_per_batch": int(cu_np[-1]),
                    "pipelined": pipelined,
@@ -529,8 +531,10 @@ def main() -> None:
                 model.set_background(True)
                 e2p = timed_loop(enc_pipe_step)
                 model.set_background(False)
-                enc2 = {"value": B * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3,
-                        "pipelined": {"value": B * args.steps / e2p, "unit": "queries/s", "ms_per_step": e2p / args.steps * 1e3}}
+                pipe2 = {"value": B * args.steps / e2p, "unit": "queries/s", "ms_per_step": e2p / args.steps * 1e3}
+                if sharded is None:   # the two-stage scan is half as long: the encoder gets 64 CUs to stay the shorter side
+                    pipe2 = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS_TWO_STAGE", "64")), pipe2)
+                enc2 = {"value": B * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3, "pipelined": pipe2}
                 step()  # leave the precomputed-embedding results in the output buffers for the comparison below
                 barrier()
             r2_s = (fin["s"] if world > 1 else out_s).cpu().numpy()
