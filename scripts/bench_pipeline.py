@@ -28,6 +28,8 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--batches", type=int, default=10)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--profile", action="store_true", help="cProfile one batch and print the top host functions")
+ap.add_argument("--no-gc", action="store_true", help="run the timed batches with the cyclic garbage collector off (diagnosis)")
+ap.add_argument("--per-batch", action="store_true", help="print every timed batch's wall time")
 a = ap.parse_args()
 
 WORDS = ("retrieval augmented generation pipeline vector index query document embedding transformer attention "
@@ -73,10 +75,18 @@ mk = lambda: Batch(1, [PendingRequest(request_id=f"r{i}", query=q, timestamp=tim
 ex._process_batch_sync(mk())  # warm
 stage_timers.reset()
 extra = {"tokenize_pairs": 0.0}
+if a.no_gc:
+    import gc
+    gc.collect(); gc.disable()
+per = []
 t0 = time.perf_counter()
 for _ in range(a.batches):
+    t1 = time.perf_counter()
     items = ex._process_batch_sync(mk())
+    per.append(time.perf_counter() - t1)
 el = time.perf_counter() - t0
+if a.per_batch:
+    print("   per batch (ms):", " ".join(f"{x * 1e3:.1f}" for x in per))
 print(f"rows={a.rows} k={a.k} rerank={a.rerank} dtype={a.dtype}: {el / a.batches * 1e3:.2f} ms/batch  {32 * a.batches / el:.0f} queries/s")
 snap = stage_timers.snapshot()
 acc = 0.0

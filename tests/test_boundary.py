@@ -472,3 +472,24 @@ def test_executor_end_to_end_through_scheduler():
         assert all(len(o.docs) == 3 for o in outs)
 
     asyncio.run(run())
+
+
+def test_executor_freezes_the_collector_once_after_its_first_batch():
+    """settings.gc_freeze_after_warmup: what is alive after the first served batch leaves the cyclic collector's sight
+    (a full collection over torch + transformers + pydantic costs 40-60 ms: one batch in ten of a rerank profile)."""
+    import gc
+    gc.unfreeze()
+    try:
+        ex, _ = _executor({"faiss_store": _Index()})
+        assert gc.get_freeze_count() == 0
+        ex._process_batch_sync(Batch(1, [_req(0, [0.5] * 4)]))
+        frozen = gc.get_freeze_count()
+        assert frozen > 0
+        ex._process_batch_sync(Batch(2, [_req(1, [1.5] * 4)]))
+        assert gc.get_freeze_count() == frozen          # once, not per batch
+        gc.unfreeze()
+        off, _ = _executor({"faiss_store": _Index()}, RAG_AMD_GC_FREEZE="false")
+        off._process_batch_sync(Batch(3, [_req(2, [2.5] * 4)]))
+        assert gc.get_freeze_count() == 0
+    finally:
+        gc.unfreeze()
