@@ -347,6 +347,12 @@ int rag_bert_range_events(rag_bert* h, int64_t* repeated_passes, int32_t* pendin
  * in HBM).  The ids are staged through pinned memory and uploaded on the handle's private stream, the forward
  * pass is enqueued behind them, and the call returns WITHOUT waiting: *stream_out is that stream (a hipStream_t),
  * on which the consumer enqueues its own work (rag_index_search_device_host_out) or which it synchronises.
+ * Batches of up to 71 sequences / ~1000 tokens with a pooled output (the query encoder) are enqueued as ONE hipGraph
+ * replay instead of 45-90 kernel launches: the shape is padded to a bucket with dummy sequences, every address in the
+ * graph is fixed, and where the result and the range flag go travels through device cells that the graph's last node
+ * reads (graphs are cached per padded shape, least recently used first out).  Halves the call's host time; results
+ * equal the eager path's to fp32 rounding (the padded token count can change a split-K choice).
+ * RAG_AMD_ENCODER_GRAPH=0 at rag_bert_create turns it off.
  * out_dev is caller-owned device memory (nseq x hidden / n_labels floats, by out_kind) and must stay allocated
  * until that stream has passed this call's work.  range_flag: as for rag_bert_forward_device. */
 int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const int32_t* type_ids,

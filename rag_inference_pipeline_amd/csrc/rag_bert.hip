@@ -17,6 +17,9 @@ namespace {
 
 constexpr int kPerLayer = 12;
 constexpr int kEmbEntries = 5;
+constexpr int kGraphTokens = 1024;   // a graphed pass holds at most this many (padded) tokens: the small-batch kernels' range
+constexpr int kGraphSeqs = 72;       // ... and this many (padded) sequences
+constexpr int kGraphCache = 24;      // instantiated graphs kept per model (least recently used goes)
 
 int weight_count(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
 
@@ -73,6 +76,26 @@ struct rag_bert {
     hipEvent_t ws_event = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_used = false;
+    // ---- the query encoder as a hipGraph (rag_bert_forward_to_device, small batches): one replay per call instead of
+    // ~45-90 kernel launches.  Shapes are padded to buckets with dummy sequences; every address in the graph is fixed:
+    // ids / type ids / cu_seqlens and three "cells" (where the result goes, where the range flag goes, how many floats)
+    // travel through one pinned block, the last node copies the pooled rows out through the cell.
+    struct EncGraph {
+        int nseq_pad, T_pad, maxlen_b, out_kind, normalize;
+        hipGraphExec_t exec;
+        unsigned long long last_use;
+    };
+    std::vector<EncGraph> graphs;
+    unsigned long long graph_clock = 0;
+    bool use_graphs = true;           // RAG_AMD_ENCODER_GRAPH=0 turns the path off
+    bool in_capture = false;          // forward_locked is being captured: no event traffic, no reallocation
+    int* g_pin = nullptr;             // pinned: [ids kGraphTokens | types kGraphTokens | cu kGraphSeqs + 1 | cells 8 ints]
+    int *g_ids = nullptr, *g_types = nullptr, *g_cu = nullptr;
+    unsigned long long* g_cells = nullptr;   // device copy of the cells: out pointer, flag pointer, float count
+    float* g_out = nullptr;           // [kGraphSeqs][hidden]
+    uint32_t* g_flag = nullptr;       // the range flag of a graph pass (device memory; published through the cell)
+    hipEvent_t g_done = nullptr;
+    bool g_used = false;
 };
 
 namespace {
@@ -350,17 +373,20 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
     using namespace ragb;
     const rag_bert_config& c = h->cfg;
     const int H = c.hidden, I = c.intermediate, heads = c.n_heads, dh = H / heads;
-    if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    if (!h->in_capture && h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
     struct Mark {  // record the workspace hand-over point on every exit path
         rag_bert* h;
         hipStream_t st;
         ~Mark() {
+            if (h->in_capture) return;   // (the graph's launcher does the event traffic around the replay)
             if (h->ws_event && hipEventRecord(h->ws_event, st) == hipSuccess) {
                 h->ws_stream = st;
                 h->ws_used = true;
             }
         }
     } mark{h, st};
+    if (h->in_capture && (T > h->ws_tokens || nseq > h->ws_seqs))
+        return ragc_fail(RAG_ERR_STATE, "workspace too small inside a graph capture");
     if (T > h->ws_tokens || nseq > h->ws_seqs) {
         // the workspace is about to be reallocated: nothing enqueued earlier (on any stream) may still use it
         if (h->ws_used) RAGC_HIP_TRY(hipEventSynchronize(h->ws_event));
@@ -623,6 +649,151 @@ int build_images(rag_bert* h, int kind) {
 }
 }  // namespace
 
+
+namespace {
+
+// Last node of an encoder graph: copy the pooled rows to where this call's caller wants them and publish the range flag.
+// Both destinations and the float count come from the cells (device memory, refreshed by the graph's first copies).
+__global__ void graph_epilogue_kernel(const float* src, const unsigned long long* cells, const uint32_t* gflag) {
+    float* dst = reinterpret_cast<float*>(cells[0]);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(cells[1]);
+    const unsigned long long n = cells[2];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flag && *gflag) *flag = 1u;
+}
+
+int ensure_graph_buffers(rag_bert* h) {
+    if (h->g_pin) return RAG_OK;
+    const size_t pin_ints = (size_t)2 * kGraphTokens + kGraphSeqs + 1 + 8;
+    RAGC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->g_pin), pin_ints * sizeof(int), hipHostMallocDefault));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_ids), kGraphTokens * sizeof(int)));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_types), kGraphTokens * sizeof(int)));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_cu), (kGraphSeqs + 1) * sizeof(int)));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_cells), 4 * sizeof(unsigned long long)));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_out), (size_t)kGraphSeqs * h->cfg.hidden * sizeof(float)));
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_flag), sizeof(uint32_t)));
+    RAGC_HIP_TRY(hipEventCreateWithFlags(&h->g_done, hipEventDisableTiming));
+    return RAG_OK;
+}
+
+// everything a graphed pass enqueues, in order; called once eagerly (first-use set-up of the kernels) and once under capture
+int graph_body(rag_bert* h, int nseq_pad, int T_pad, int maxlen_b, int out_kind, int normalize, hipStream_t st) {
+    int* pin_ids = h->g_pin;
+    int* pin_types = h->g_pin + kGraphTokens;
+    int* pin_cu = h->g_pin + 2 * kGraphTokens;
+    int* pin_cells = h->g_pin + 2 * kGraphTokens + kGraphSeqs + 1;
+    RAGC_HIP_TRY(hipMemcpyAsync(h->g_ids, pin_ids, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->g_types, pin_types, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->g_cu, pin_cu, (size_t)(nseq_pad + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->g_cells, pin_cells, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipMemsetAsync(h->g_flag, 0, sizeof(uint32_t), st));
+    int rc = forward_locked(h, h->g_ids, h->cfg.type_vocab > 0 ? h->g_types : nullptr, h->g_cu, nseq_pad, T_pad, maxlen_b, out_kind,
+                            normalize, h->g_out, st, h->g_flag);
+    if (rc) return rc;
+    graph_epilogue_kernel<<<dim3(32), dim3(256), 0, st>>>(h->g_out, h->g_cells, h->g_flag);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
+// the graph for a padded shape: from the cache, or captured now (after one eager run of the same body)
+int get_graph(rag_bert* h, int nseq_pad, int T_pad, int maxlen_b, int out_kind, int normalize, hipStream_t st, hipGraphExec_t* out) {
+    for (auto& g : h->graphs)
+        if (g.nseq_pad == nseq_pad && g.T_pad == T_pad && g.maxlen_b == maxlen_b && g.out_kind == out_kind && g.normalize == normalize) {
+            g.last_use = ++h->graph_clock;
+            *out = g.exec;
+            return RAG_OK;
+        }
+    // first use of this shape: make sure the workspace fits and every kernel has had its one-time set-up, eagerly
+    if (T_pad > h->ws_tokens || nseq_pad > h->ws_seqs) {
+        if (h->ws_used) RAGC_HIP_TRY(hipEventSynchronize(h->ws_event));
+        RAGC_HIP_TRY(hipStreamSynchronize(st));
+        int rc = ensure_ws(h, T_pad, nseq_pad);
+        if (rc) return rc;
+    }
+    int rc = graph_body(h, nseq_pad, T_pad, maxlen_b, out_kind, normalize, st);   // (writes through the cells: harmless, the replay follows)
+    if (rc) return rc;
+    RAGC_HIP_TRY(hipStreamSynchronize(st));
+    hipGraph_t graph = nullptr;
+    RAGC_HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    h->in_capture = true;
+    rc = graph_body(h, nseq_pad, T_pad, maxlen_b, out_kind, normalize, st);
+    h->in_capture = false;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return rc ? rc : ragc_fail(RAG_ERR_HIP, "capturing the encoder graph failed: %s", hipGetErrorString(e));
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return ragc_fail(RAG_ERR_HIP, "instantiating the encoder graph failed: %s", hipGetErrorString(ei));
+    if ((int)h->graphs.size() >= kGraphCache) {   // evict the least recently used
+        size_t victim = 0;
+        for (size_t i = 1; i < h->graphs.size(); ++i)
+            if (h->graphs[i].last_use < h->graphs[victim].last_use) victim = i;
+        RAGC_HIP_TRY(hipStreamSynchronize(st));
+        (void)hipGraphExecDestroy(h->graphs[victim].exec);
+        h->graphs.erase(h->graphs.begin() + (long)victim);
+    }
+    h->graphs.push_back(rag_bert::EncGraph{nseq_pad, T_pad, maxlen_b, out_kind, normalize, exec, ++h->graph_clock});
+    *out = exec;
+    return RAG_OK;
+}
+
+// rag_bert_forward_to_device through a graph.  Returns kNotGraphed when the batch does not qualify (the caller takes the
+// eager path).
+constexpr int kNotGraphed = -1;
+int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type_ids, const int32_t* cu, int nseq, int T, int max_len,
+                            int out_kind, int normalize, float* out_dev, uint32_t* range_flag, hipStream_t st) {
+    if (!h->use_graphs || h->background || (out_kind != RAG_BERT_OUT_MEAN && out_kind != RAG_BERT_OUT_CLS)) return kNotGraphed;
+    // padding: at least one dummy sequence, sequences to a multiple of 8, tokens to a multiple of 64 (every dummy >= 1 token)
+    const int nseq_pad = (nseq + 1 + 7) / 8 * 8, n_dummy = nseq_pad - nseq;
+    const int T_pad = (T + n_dummy + 63) / 64 * 64;
+    if (nseq_pad > kGraphSeqs || T_pad > kGraphTokens) return kNotGraphed;
+    const int extra = T_pad - T;                                  // tokens the dummies hold
+    const int dummy_len = (extra + n_dummy - 1) / n_dummy;        // the longest dummy
+    if (dummy_len + h->cfg.pos_offset > h->cfg.max_positions) return kNotGraphed;
+    const int maxlen_b = (std::max(max_len, dummy_len) + 31) / 32 * 32;
+    int rc = ensure_graph_buffers(h);
+    if (rc) return rc;
+    if (h->g_used) RAGC_HIP_TRY(hipEventSynchronize(h->g_done));   // the previous graphed pass has left the pinned block and the buffers
+    int* pin_ids = h->g_pin;
+    int* pin_types = h->g_pin + kGraphTokens;
+    int* pin_cu = h->g_pin + 2 * kGraphTokens;
+    unsigned long long* pin_cells = reinterpret_cast<unsigned long long*>(h->g_pin + 2 * kGraphTokens + kGraphSeqs + 1);
+    std::memcpy(pin_ids, ids, (size_t)T * sizeof(int));
+    std::memset(pin_ids + T, 0, (size_t)extra * sizeof(int));
+    if (type_ids) std::memcpy(pin_types, type_ids, (size_t)T * sizeof(int));
+    else std::memset(pin_types, 0, (size_t)T * sizeof(int));
+    std::memset(pin_types + T, 0, (size_t)extra * sizeof(int));
+    std::memcpy(pin_cu, cu, (size_t)(nseq + 1) * sizeof(int));
+    for (int i = 0, at = T, left = extra; i < n_dummy; ++i) {   // dummies share the padding tokens as evenly as possible
+        const int len = (left + (n_dummy - i) - 1) / (n_dummy - i);
+        at += len;
+        left -= len;
+        pin_cu[nseq + 1 + i] = at;
+    }
+    pin_cells[0] = reinterpret_cast<unsigned long long>(out_dev);
+    pin_cells[1] = reinterpret_cast<unsigned long long>(range_flag);
+    pin_cells[2] = (unsigned long long)nseq * h->cfg.hidden;
+    hipGraphExec_t exec = nullptr;
+    rc = get_graph(h, nseq_pad, T_pad, maxlen_b, out_kind, normalize, st, &exec);
+    if (rc) return rc;
+    if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    RAGC_HIP_TRY(hipGraphLaunch(exec, st));
+    if (hipEventRecord(h->ws_event, st) == hipSuccess) {
+        h->ws_stream = st;
+        h->ws_used = true;
+    }
+    RAGC_HIP_TRY(hipEventRecord(h->g_done, st));
+    h->g_used = true;
+    return RAG_OK;
+}
+
+}  // namespace
+
 extern "C" int32_t rag_bert_weight_count(const rag_bert_config* cfg) { return cfg ? weight_count(*cfg) : 0; }
 
 extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* weights_dev, int32_t n_weights,
@@ -672,6 +843,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     h->valu_attention = va && *va == '1';
     const char* rm = getenv("RAG_AMD_ROW_MAJOR");
     h->row_major_only = rm && *rm == '1';
+    const char* eg = getenv("RAG_AMD_ENCODER_GRAPH");
+    h->use_graphs = !(eg && *eg == '0');
     const char* ta = getenv("RAG_AMD_TILED_ATTENTION_F32");
     h->tiled_attention_f32 = ta && *ta == '1';
     if (hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
@@ -719,6 +892,12 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
             if (p) (void)hipFree(p);
         for (_Float16* p : h->wxf)
             if (p) (void)hipFree(p);
+        for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+        void* gptrs[] = {h->g_ids, h->g_types, h->g_cu, h->g_cells, h->g_out, h->g_flag};
+        for (void* p : gptrs)
+            if (p) (void)hipFree(p);
+        if (h->g_pin) (void)hipHostFree(h->g_pin);
+        if (h->g_done) (void)hipEventDestroy(h->g_done);
         if (h->range_pin) (void)hipHostFree(h->range_pin);
         if (h->stage_pin) (void)hipHostFree(h->stage_pin);
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);
@@ -774,6 +953,14 @@ extern "C" int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const
     RagcDeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t st = h->stream;
+    // small batches (the query encoder): one graph replay instead of ~45-90 launches
+    rc = forward_to_device_graph(h, ids, type_ids, cu_seqlens, nseq, T, max_len, out_kind, normalize, out_dev,
+                                 range_flag ? range_flag : h->range_pin, st);
+    if (rc == RAG_OK) {
+        *stream_out = (void*)st;
+        return RAG_OK;
+    }
+    if (rc != kNotGraphed) return rc;
     rc = grow(&h->ids_dev, &h->ids_cap, (long long)T);
     if (rc) return rc;
     if (type_ids && (rc = grow(&h->types_dev, &h->types_cap, (long long)T))) return rc;

@@ -331,3 +331,42 @@ def test_background_mode_gives_the_same_embeddings(gpu_required):
     np.testing.assert_allclose(bg, want, atol=1e-5)
     np.testing.assert_allclose(base, want, atol=1e-5)
     np.testing.assert_array_equal(again.view(np.uint32), base.view(np.uint32))   # switching back restores the default form
+
+
+def test_query_encoder_replays_a_graph_per_padded_shape(gpu_required, monkeypatch):
+    """rag_bert_forward_to_device on small batches (the query encoder): one hipGraph replay per call — shapes padded to
+    buckets with dummy sequences, destinations passed through device cells — returns what the eager launches return
+    (to fp32 rounding: the padded token count can change a split-K choice), for new shapes, cached shapes, shapes beyond
+    the cache's capacity, mean and first-token pooling, with and without normalisation."""
+    cfg = _small(BertConfig.minilm_l6())
+    cfg.n_layers = 2
+    w = random_weights(cfg, 31)
+    graphed = BertModel(cfg, w)
+    monkeypatch.setenv("RAG_AMD_ENCODER_GRAPH", "0")
+    eager = BertModel(cfg, w)
+    monkeypatch.delenv("RAG_AMD_ENCODER_GRAPH")
+    rng = np.random.default_rng(31)
+    shapes = [(n, lo, hi) for n in (1, 3, 11, 19, 32, 40) for lo, hi in ((2, 9), (8, 21), (10, 26))]   # 18+ padded shapes
+    shapes += [(64, 8, 15), (7, 100, 140)]          # 64 sequences; 1000+ tokens: beyond the graph's range -> eager inside
+    for rep in range(2):
+        for n, lo, hi in shapes:
+            seqs = _seqs(rng, rng.integers(lo, hi, size=n), cfg.vocab_size)
+            types = [[0] * len(q) for q in seqs]
+            for pooling, normalize in (("mean", True), ("cls", False)):
+                a = graphed.embed_to_device(seqs, types, normalize=normalize, pooling=pooling)
+                b = eager.embed_to_device(seqs, types, normalize=normalize, pooling=pooling)
+                got, ref = a.numpy(), b.numpy()
+                assert a.valid() and b.valid()
+                np.testing.assert_allclose(got, ref, atol=3e-6, rtol=1e-5)
+                if rep == 0 and n in (3, 32):
+                    np.testing.assert_allclose(got, obert.embed(cfg, w, seqs, types, normalize=normalize, pooling=pooling),
+                                               atol=1e-5 if normalize else 5e-5, rtol=1e-4)
+    # back-to-back calls without reading the first result first: the second waits for the first's buffers itself
+    s1 = _seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size)
+    s2 = _seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size)
+    a1 = graphed.embed_to_device(s1, [[0] * len(q) for q in s1])
+    a2 = graphed.embed_to_device(s2, [[0] * len(q) for q in s2])
+    np.testing.assert_allclose(a2.numpy(), eager.embed(s2, [[0] * len(q) for q in s2]), atol=3e-6, rtol=1e-5)
+    np.testing.assert_allclose(a1.numpy(), eager.embed(s1, [[0] * len(q) for q in s1]), atol=3e-6, rtol=1e-5)
+    graphed.close()
+    eager.close()
