@@ -129,6 +129,12 @@ def cpu_baseline(args: argparse.Namespace) -> dict:
 
 def main() -> None:
     args = parse_args()
+    # Exactly ONE line on stdout, the JSON: libraries write to file descriptor 1 on their own (RCCL prints a version
+    # banner when its first communicator comes up, gloo its rank lines), so everything but the result goes to stderr:
+    # fd 1 is pointed at stderr for the run and the line is written to the original stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -643,7 +649,8 @@ def main() -> None:
             out["rerank_stage"] = rerank_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     index.close()
     if dist is not None:
