@@ -135,6 +135,46 @@ def test_config_c_rerank_top100_to_top10_3200_pairs(corpus_and_index, encoded_qu
                 assert full[b][r].doc_id == int(I[b][j])
 
 
+def test_config_c_in_the_references_gpu_precision_3200_pairs(corpus_and_index, encoded_queries):
+    """Config C with `RAG_AMD_RERANKER_DTYPE=f16` — the precision the reference runs its reranker at on a GPU
+    (reranker.py:91-93) — at full size: 3200 pairs through fp16 activations stored in MFMA-fragment order.  The rerank
+    contract is the same (stable descending sort, `top_n` slices it); scores stay within half precision's reach of the
+    fp32 oracle (5e-3 on sigmoid scores, the bar of test_cross_encoder_fp16_gemm_mode_tracks_fp32_oracle), and a
+    document the oracle ranks clearly first (by more than twice that) is ranked first."""
+    from rag_inference_pipeline_amd.components.reranker import Reranker
+    from rag_inference_pipeline_amd.components.schemas import Document
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    from rag_inference_pipeline_amd.model_source import resolve_model
+    X, idx = corpus_and_index
+    queries, emb, _ = encoded_queries
+    _, I = idx.search(emb, 100)
+    docs_batch = [[Document(doc_id=int(i), title=f"Document {int(i)}", content=_doc_text(int(i)), category="general")
+                   for i in row] for row in I]
+    name = "synthetic:ms-marco-MiniLM-L-6-v2:12"
+    rr = Reranker(PipelineSettings(reranker_model_name=name, RAG_AMD_RERANKER_DTYPE="f16"))
+    rr.load()
+    assert rr.model.cfg.gemm_dtype == "f16"
+    full = rr.rerank_batch(queries, docs_batch)
+    top10 = rr.rerank_batch(queries, docs_batch, top_n=10)
+    rr.unload()
+    assert len(full) == B and all(len(r) == 100 for r in full) and all(len(r) == 10 for r in top10)
+    for b in range(B):
+        scores = [d.score for d in full[b]]
+        assert scores == sorted(scores, reverse=True) and all(0.0 <= s <= 1.0 for s in scores)
+        assert sorted(d.doc_id for d in full[b]) == sorted(I[b].tolist())
+        assert [(d.doc_id, d.score) for d in top10[b]] == [(d.doc_id, d.score) for d in full[b][:10]]
+    cfg, w, tok, max_len = resolve_model(name, "reranker")
+    for b in (0, 13, 31):
+        pids, ptypes = tok.encode_pairs([queries[b]] * 100, [d.content for d in docs_batch[b]], min(512, max_len))
+        want = obert.classify(cfg, w, pids, ptypes)[:, 0]
+        got = {d.doc_id: d.score for d in full[b]}
+        diffs = [abs(got[int(i)] - float(s)) for i, s in zip(I[b], want)]
+        assert max(diffs) < 5e-3, max(diffs)
+        order = sorted(range(100), key=lambda j: float(want[j]), reverse=True)
+        if float(want[order[0]]) - float(want[order[1]]) > 1e-2:
+            assert full[b][0].doc_id == int(I[b][order[0]])
+
+
 def test_config_b_size_on_the_surveys_gaussian_corpus(gpu_required):
     """SURVEY 8(d)'s synthetic inputs, literally: corpus rows from `np.random.default_rng(1234 + chunk)
     .standard_normal` in chunks, L2-normalised; queries from `default_rng(4321)`; a second query set of perturbed
