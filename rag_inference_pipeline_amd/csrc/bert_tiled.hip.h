@@ -3,11 +3,12 @@
 // fp32.  Same arithmetic as their row-major counterparts in bert_kernels.hip.h (fp32 inside; E is only how a value
 // is stored), reference: src/pipeline/components/reranker.py:248-252 and embedding.py:127-133 (the model's forward).
 //
-// A token's row is scattered over the fragments of its 32-token row block, so the row-wise kernels work per ROW BLOCK:
-// a workgroup moves the block between memory and a row-major LDS image with whole-fragment (1 KiB, coalesced)
-// transfers and does the row arithmetic on the LDS image, one wave per eight tokens, exactly as the row-major kernels
-// do it in registers.  LDS rows are padded by four floats: fragment-shaped accesses (32 lanes, 32 different rows, the
-// same columns) then fall into distinct banks.
+// A token's row is scattered over the fragments of its 32-token row block, so the row-wise kernels (embedding +
+// LayerNorm, LayerNorm) work per ROW BLOCK with whole-fragment (1 KiB, coalesced) loads and stores: wave w of the block's
+// workgroup takes the 16-feature steps w, w + 4, ..., a lane keeps its token's values of those steps in registers, and a
+// token's sums are its two lanes' (one shuffle) over the four waves' (128 floats of LDS).  Only the copy out to row-major
+// fp32 (untile_kernel) goes through an LDS row image (rows padded by four floats: fragment-shaped accesses — 32 lanes, 32
+// different rows, the same columns — then fall into distinct banks).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,7 +37,7 @@ __device__ __forceinline__ void tiled_store4(E* x, long long m, int f, int F, co
 
 constexpr int kRowPad = 4;   // floats
 
-// LDS image [32][H + kRowPad] fp32  <->  row block `rb` of a tiled [.][H] matrix; all 256 threads, whole fragments
+// LDS image [32][H + kRowPad] fp32  <-  row block `rb` of a tiled [.][H] matrix; all 256 threads, whole fragments
 template <typename E>
 __device__ __forceinline__ void block_to_lds(const E* x, int rb, int H, float* rows, int tid) {
     const int ld = H + kRowPad, nks = H >> 4;
@@ -54,68 +55,6 @@ __device__ __forceinline__ void block_to_lds(const E* x, int rb, int H, float* r
         }
     }
 }
-template <typename E>
-__device__ __forceinline__ void lds_to_block(const float* rows, E* x, int rb, int H, int tid) {
-    const int ld = H + kRowPad, nks = H >> 4;
-    for (int i = tid; i < nks * 64; i += 256) {
-        const int ks = i >> 6, l = i & 63, r = l & 31, h = l >> 5;
-        const float* src = rows + r * ld + 16 * ks + 8 * h;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
-        if constexpr (sizeof(E) == 2) {
-            const f16x8 v = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3],
-                             (_Float16)b[0], (_Float16)b[1], (_Float16)b[2], (_Float16)b[3]};
-            *reinterpret_cast<f16x8*>(x + ((size_t)rb * nks + ks) * 512 + l * 8) = v;
-        } else {
-            float* dst = x + ((size_t)rb * nks + ks) * 512 + l * 4;
-            *reinterpret_cast<f32x4*>(dst) = a;
-            *reinterpret_cast<f32x4*>(dst + 256) = b;
-        }
-    }
-}
-
-// Embeddings + LayerNorm, one workgroup (4 waves) per row block; the per-token arithmetic is embed_ln_kernel's.
-// Rows past T are written as zeros.  Dynamic LDS: 32 (H + 4) floats.
-template <typename E>
-__global__ __launch_bounds__(256) void embed_ln_tiled_kernel(const EmbedParams p, E* out) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* rows = reinterpret_cast<float*>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = blockIdx.x, ld = p.H + kRowPad;
-    const int nch = p.H >> 2;
-    for (int i = 0; i < 8; ++i) {
-        const int row = wave * 8 + i, t = rb * 32 + row;
-        float* o = rows + row * ld;
-        if (t >= p.T) {
-            for (int ch = lane; ch < nch; ch += 64) *reinterpret_cast<f32x4*>(o + 4 * ch) = f32x4{0.f, 0.f, 0.f, 0.f};
-            continue;
-        }
-        const int s = find_seq(p.cu, p.nseq, t);
-        int pos = t - p.cu[s] + p.pos_offset;
-        pos = pos < p.max_pos ? pos : p.max_pos - 1;
-        int id = p.ids[t];
-        id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
-        int ty = p.type_ids ? p.type_ids[t] : 0;
-        ty = ty < 0 ? 0 : (ty >= p.type_vocab ? p.type_vocab - 1 : ty);
-        const float* w = p.word_emb + (size_t)id * p.H;
-        const float* pe = p.pos_emb + (size_t)pos * p.H;
-        const float* te = p.type_emb ? p.type_emb + (size_t)ty * p.H : nullptr;
-        f32x4 v[kMaxChunks];
-#pragma unroll
-        for (int j = 0; j < kMaxChunks; ++j) {
-            const int ch = lane + 64 * j;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (ch < nch) {
-                x = *reinterpret_cast<const f32x4*>(w + 4 * ch) + *reinterpret_cast<const f32x4*>(pe + 4 * ch);
-                if (te) x += *reinterpret_cast<const f32x4*>(te + 4 * ch);
-            }
-            v[j] = x;
-        }
-        ln_store(v, lane, p.H, p.eps, p.ln_g, p.ln_b, o);
-    }
-    __syncthreads();
-    lds_to_block(rows, out, rb, p.H, tid);
-}
-
 // a lane's eight values of fragment (rb, ks): token 32 rb + (lane & 31), features 16 ks + 8 (lane >> 5) + 0..7
 template <typename E>
 __device__ __forceinline__ void frag_load8(const E* x, size_t frag, int lane, float (&v)[8]) {
@@ -140,6 +79,87 @@ __device__ __forceinline__ void frag_store8(E* x, size_t frag, int lane, const f
     } else {
         *reinterpret_cast<f32x4*>(x + frag * 512 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<f32x4*>(x + frag * 512 + 256 + lane * 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// Embeddings + LayerNorm, one workgroup (4 waves) per row block, built like ln_tiled_kernel below: wave w takes the
+// 16-feature steps w, w + 4, ..., lane (r, h) gathers token r's eight features of a step from the word / position / type
+// tables (32 contiguous bytes per table), keeps them in registers, and a token's sums are its two lanes' over the four
+// waves'.  Rows past T are written as zeros.  NK = steps per wave = ceil(H / 64).  (The first form did the row
+// arithmetic on an LDS row image with one wave per eight tokens: 1.2 TB/s; this one 3x that.)
+template <typename E, int NK>
+__global__ __launch_bounds__(256) void embed_ln_tiled_kernel(const EmbedParams p, E* out) {
+    __shared__ float red[2][4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int rb = blockIdx.x, nks = p.H >> 4;
+    const size_t f0 = (size_t)rb * nks;
+    const int t = rb * 32 + r;
+    const bool live = t < p.T;
+    const float *w = nullptr, *pe = nullptr, *te = nullptr;
+    if (live) {
+        const int s = find_seq(p.cu, p.nseq, t);
+        int pos = t - p.cu[s] + p.pos_offset;
+        pos = pos < p.max_pos ? pos : p.max_pos - 1;
+        int id = p.ids[t];
+        id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
+        int ty = p.type_ids ? p.type_ids[t] : 0;
+        ty = ty < 0 ? 0 : (ty >= p.type_vocab ? p.type_vocab - 1 : ty);
+        w = p.word_emb + (size_t)id * p.H;
+        pe = p.pos_emb + (size_t)pos * p.H;
+        te = p.type_emb ? p.type_emb + (size_t)ty * p.H : nullptr;
+    }
+    float v[NK][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int ks = wave + 4 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (ks < nks && live) {
+            const int f = 16 * ks + 8 * h;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(w + f) + *reinterpret_cast<const f32x4*>(pe + f);
+            f32x4 a1 = *reinterpret_cast<const f32x4*>(w + f + 4) + *reinterpret_cast<const f32x4*>(pe + f + 4);
+            if (te) {
+                a0 += *reinterpret_cast<const f32x4*>(te + f);
+                a1 += *reinterpret_cast<const f32x4*>(te + f + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] = a0[e]; v[i][4 + e] = a1[e]; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[i][e];
+        }
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    if (h == 0) red[0][wave][r] = sum;
+    __syncthreads();
+    const float mean = ((red[0][0][r] + red[0][1][r]) + (red[0][2][r] + red[0][3][r])) / (float)p.H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK; ++i)
+        if (wave + 4 * i < nks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[i][e] - mean;
+                q = __builtin_fmaf(d, d, q);
+            }
+        }
+    q += __shfl_xor(q, 32, 64);
+    if (h == 0) red[1][wave][r] = q;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[1][0][r] + red[1][1][r]) + (red[1][2][r] + red[1][3][r])) / (float)p.H + p.eps);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int ks = wave + 4 * i;
+        if (ks < nks) {
+            const int f = 16 * ks + 8 * h;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_g + f), g1 = *reinterpret_cast<const f32x4*>(p.ln_g + f + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_b + f), b1 = *reinterpret_cast<const f32x4*>(p.ln_b + f + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = live ? (v[i][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]) : 0.f;
+            frag_store8(out, f0 + ks, lane, o);
+        }
     }
 }
 

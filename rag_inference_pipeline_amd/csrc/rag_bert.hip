@@ -436,8 +436,9 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         else hipLaunchKernelGGL((ln_tiled_kernel<half_t, 16>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
     };
     if (tiled) {
-        if ((rc = ensure_lds(reinterpret_cast<const void*>(&embed_ln_tiled_kernel<half_t>), row_lds))) return rc;
-        hipLaunchKernelGGL(embed_ln_tiled_kernel<half_t>, dim3(nrb), dim3(256), row_lds, st, ep, xh);
+        if (H <= 384) hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 6>), dim3(nrb), dim3(256), 0, st, ep, xh);
+        else if (H <= 768) hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 12>), dim3(nrb), dim3(256), 0, st, ep, xh);
+        else hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 16>), dim3(nrb), dim3(256), 0, st, ep, xh);
     } else {
         embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
     }
