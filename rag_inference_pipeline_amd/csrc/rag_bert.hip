@@ -1063,7 +1063,15 @@ extern "C" int rag_bert_set_cu_budget(rag_bert* h, int32_t n_cus) {
     if (n_cus < 0 || n_cus > prop.multiProcessorCount)
         return ragc_fail(RAG_ERR_INVALID_ARG, "CU budget %d outside [0, %d]", n_cus, prop.multiProcessorCount);
     std::lock_guard<std::mutex> lk(h->mu);
-    h->n_cus = n_cus == 0 ? prop.multiProcessorCount : n_cus;
+    const int want = n_cus == 0 ? prop.multiProcessorCount : n_cus;
+    if (want != h->n_cus && !h->graphs.empty()) {
+        // cached encoder graphs carry the tile and split-K choices of the old budget: drop them (after their last replay)
+        RagcDeviceGuard g(h->device);
+        RAGC_HIP_TRY(hipDeviceSynchronize());
+        for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
+        h->graphs.clear();
+    }
+    h->n_cus = want;
     return RAG_OK;
 }
 
