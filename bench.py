@@ -111,6 +111,26 @@ def cpu_baseline(args: argparse.Namespace) -> dict:
         r2, e2 = _time_cpu(lambda: oracle.search(X, Q, args.k, nthreads=all_threads), 6.0, 20)
         out["all_cores"] = {"value": args.batch * r2 / e2 * scale, "unit": "queries/s", "cores": all_threads,
                             "ms_per_batch_on_sample": e2 / r2 * 1e3}
+    # The same sample through an optimised BLAS: numpy's sgemm (OpenBLAS) on the same 16 threads + argpartition / sort
+    # top-k — the algorithm family faiss IndexFlat uses for batches of 20 queries and more.  Reported beside the port
+    # (which fixes a summation order for bit-exact parity and is slower for it); neither is the optimisation target.
+    try:
+        from threadpoolctl import threadpool_limits
+
+        def sgemm_search():
+            S = Q @ X.T
+            part = np.argpartition(-S, args.k - 1, axis=1)[:, :args.k]
+            top = np.take_along_axis(S, part, axis=1)
+            order = np.argsort(-top, axis=1, kind="stable")
+            return np.take_along_axis(part, order, axis=1)
+
+        with threadpool_limits(limits=cores):
+            r4, e4 = _time_cpu(sgemm_search, 5.0, 20)
+        out["sgemm"] = {"value": args.batch * r4 / e4 * scale, "unit": "queries/s", "cores": cores,
+                        "ms_per_batch_on_sample": e4 / r4 * 1e3,
+                        "how": "numpy (OpenBLAS sgemm) Q @ X.T + argpartition + sort on the same sample and thread count"}
+    except Exception as exc:  # noqa: BLE001
+        out["sgemm"] = f"not measured ({type(exc).__name__}: {exc})"
     try:
         import faiss  # noqa: F401  (probe: the GPU box receives only this repo, faiss may or may not be there)
     except Exception as exc:  # noqa: BLE001
