@@ -370,3 +370,39 @@ def test_query_encoder_replays_a_graph_per_padded_shape(gpu_required, monkeypatc
     np.testing.assert_allclose(a1.numpy(), eager.embed(s1, [[0] * len(q) for q in s1]), atol=3e-6, rtol=1e-5)
     graphed.close()
     eager.close()
+
+
+@pytest.mark.parametrize("hidden,heads,inter,head,seed", [
+    (256, 8, 672, "none", 41),        # DH 32, N = 672 = 5.25 tiles of 128, K = 256
+    (512, 8, 1568, "bert", 42),       # DH 64, intermediate 1568 (not a multiple of 64): K >= 1536 on the way back
+    (1024, 16, 2080, "roberta", 43),  # the widest row the kernels take; RoBERTa framing (pos_offset 2, one token type)
+    (384, 6, 96, "none", 44),         # DH 64 with a tiny feed-forward (N = 96 < one tile)
+])
+def test_fp16_fragment_order_path_on_odd_shapes(gpu_required, hidden, heads, inter, head, seed):
+    """The fragment-ordered fp16 data path away from the two model shapes it is tuned on: widths that are not whole
+    tiles, both head sizes, K on both sides of the two-step kernel's threshold, sequences of several key tiles and a
+    token count that is not a whole row block — hidden states, pooled embeddings and (with a head) logits against
+    the fp32 oracle within half precision's reach."""
+    cfg = BertConfig(hidden=hidden, n_layers=2, n_heads=heads, intermediate=inter, vocab_size=1500, head=head,
+                     n_labels=1 if head != "none" else 1, pooling="cls" if seed % 2 else "mean")
+    if head == "roberta":
+        cfg.max_positions, cfg.type_vocab, cfg.pos_offset, cfg.ln_eps = 514, 1, 2, 1e-5
+    cfg.gemm_dtype = "f16"
+    w = random_weights(cfg, seed)
+    rng = np.random.default_rng(seed)
+    seqs = _seqs(rng, [300, 1, 129, 97, 33, 2, 200, 64, 250, 31, 5, 160], cfg.vocab_size)   # 1272 tokens
+    assert sum(map(len, seqs)) > 1024 and sum(map(len, seqs)) % 32 != 0
+    types = [[0] * len(s) for s in seqs] if cfg.type_vocab == 1 else [[0] * (len(s) // 2) + [1] * (len(s) - len(s) // 2) for s in seqs]
+    model = BertModel(cfg, w)
+    want_h = np.concatenate(obert.hidden_states(cfg, w, seqs, types))
+    got_h = model.hidden_states(seqs, types)
+    scale = max(1.0, np.abs(want_h).max())
+    assert np.isfinite(got_h).all()
+    assert np.abs(got_h - want_h).max() < 3e-2 * scale, np.abs(got_h - want_h).max()
+    want_e = obert.embed(cfg, w, seqs, types)
+    assert np.abs(model.embed(seqs, types) - want_e).max() < 2e-2
+    if head != "none":
+        want_l = obert.classify(cfg, w, seqs, types, sigmoid=False)
+        got_l = model.classify(seqs, types, sigmoid=False)
+        assert np.abs(got_l - want_l).max() < 3e-2 * max(1.0, np.abs(want_l).max())
+    model.close()
