@@ -178,6 +178,9 @@ int rag_index_profile(rag_index* h, double* scan_ms_total, int64_t* scan_launche
  * with_query_encoder.pipelined).  Results do not depend on either setting. */
 int rag_stream_create_masked(int32_t device, int32_t first_cu, int32_t n_cus, void** stream_out);
 int rag_stream_destroy(int32_t device, void* stream);
+/* Work enqueued on `waiter` after this call starts only when what is on `signaler` now has finished. */
+int rag_stream_wait(int32_t device, void* waiter, void* signaler);
+int rag_device_cu_count(int32_t device, int32_t* n_cus);
 int rag_index_set_cu_budget(rag_index* h, int32_t n_cus);
 /* (rag_bert_set_cu_budget is declared with the rag_bert entry points below.) */
 
@@ -335,6 +338,11 @@ int rag_bert_set_background(rag_bert* h, int32_t on);
 
 /* CUs this model's launches may count on; 0 = the whole device (see rag_stream_create_masked). */
 int rag_bert_set_cu_budget(rag_bert* h, int32_t n_cus);
+
+/* The stream the host-ids entry points (rag_bert_forward, rag_bert_forward_to_device) enqueue on, instead of the
+ * handle's own; NULL restores that.  The caller owns it and keeps it alive until it is replaced or the handle destroyed
+ * (components/embedding.py: a stream restricted to the encoder's share of the chip, RAG_AMD_ENCODER_CUS). */
+int rag_bert_set_stream(rag_bert* h, void* stream);
 
 /* Passes the host-pointer entry point has repeated on the three-plane path because an activation left fp16's range
  * (RAG_GEMM_F32, see above).  `pending` (may be NULL; synchronises the device when given): 1 when a pass of one of the

@@ -142,6 +142,9 @@ def _declare(lib: C.CDLL) -> None:
         "rag_bert_range_events": (C.c_int, [vp, i64p, i32p]),
         "rag_bert_set_background": (C.c_int, [vp, C.c_int32]),
         "rag_bert_set_cu_budget": (C.c_int, [vp, C.c_int32]),
+        "rag_bert_set_stream": (C.c_int, [vp, C.c_void_p]),
+        "rag_stream_wait": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),
+        "rag_device_cu_count": (C.c_int, [C.c_int32, C.POINTER(C.c_int32)]),
         "rag_index_set_cu_budget": (C.c_int, [vp, C.c_int32]),
         "rag_stream_create_masked": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
         "rag_stream_destroy": (C.c_int, [C.c_int32, C.c_void_p]),

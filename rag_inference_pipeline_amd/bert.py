@@ -326,6 +326,11 @@ class BertModel:
         kernel such as the corpus scan (rag_bert_set_background)."""
         _native.check(self._lib.rag_bert_set_background(self._h, 1 if on else 0))
 
+    def set_stream(self, stream: int = 0) -> None:
+        """The stream embed() / embed_to_device() / classify() enqueue on instead of the model's own (0 restores it);
+        the caller keeps it alive (rag_bert_set_stream)."""
+        _native.check(self._lib.rag_bert_set_stream(self._h, C.c_void_p(int(stream)) if stream else None))
+
     def set_cu_budget(self, n_cus: int = 0) -> None:
         """How many compute units this model's launches may count on (0 = the whole device): for a caller that runs it
         on a stream restricted to a share of the chip (rag_stream_create_masked)."""

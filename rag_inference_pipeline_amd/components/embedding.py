@@ -59,6 +59,15 @@ class EmbeddingGenerator:
             self.device = f"cuda:{self._device_index}"
             self._model = BertModel(cfg, weights, device=self._device_index)
             self._tokenizer, self._max_len = tokenizer, max_len
+            self._share_stream = 0
+            share = int(getattr(self.settings, "encoder_cus", 0) or 0)
+            if share > 0 and self._dist_world() == 1:
+                # the encoder's share of the chip (settings.encoder_cus): its passes run on these CUs only, beside
+                # whatever the index's search stream runs on the others (components/faiss_store.py)
+                from ..flat_index import create_masked_stream
+                self._share_stream = create_masked_stream(self._device_index, 0, share)
+                self._model.set_stream(self._share_stream)
+                self._model.set_cu_budget(share)
             self._is_loaded = True
             # warm-up on a longer text, as the reference does (:84-93)
             self._encode_uncached(["This is a test sentence for warmup. " * 10])
@@ -68,6 +77,14 @@ class EmbeddingGenerator:
             self._model = None
             self._is_loaded = False
             raise
+
+    @staticmethod
+    def _dist_world() -> int:
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return 1
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def _encode_uncached(self, texts: list[str]) -> np.ndarray:
         ids, types = self._tokenizer.encode_batch(texts, self._max_len)
@@ -129,6 +146,10 @@ class EmbeddingGenerator:
             logger.info("Unloading embedding model")
             if self._model is not None:
                 self._model.close()
+            if getattr(self, "_share_stream", 0):
+                from ..flat_index import destroy_stream
+                destroy_stream(self._device_index, self._share_stream)
+                self._share_stream = 0
             self._model = None
             self._tokenizer = None
             self._is_loaded = False

@@ -48,6 +48,22 @@ class FAISSStore:
         self._sharded = None  # rag_inference_pipeline_amd.sharded.ShardedFlatIndex when world > 1
         self._ntotal = 0
         self._is_loaded = False
+        self._share_stream = 0     # the search stream of a partitioned chip (settings.encoder_cus), made at first use
+        self._share_checked = False
+
+    def _search_share(self) -> int:
+        """settings.encoder_cus > 0 on one GPU: searches that follow the embedder on the device run on a stream that owns
+        the CUs the encoder's stream does not, and the index plans its launches for that many (0: no partition)."""
+        if not self._share_checked:
+            self._share_checked = True
+            share = int(getattr(self.settings, "encoder_cus", 0) or 0)
+            if share > 0 and self._sharded is None and self._index is not None:
+                from ..flat_index import create_masked_stream, device_cu_count
+                total = device_cu_count(self._index.device)
+                if 0 < share < total:
+                    self._share_stream = create_masked_stream(self._index.device, share, total - share)
+                    self._index.set_cu_budget(total - share)
+        return self._share_stream
 
     def load(self) -> None:
         """Read the index file and pin its rows in HBM (reference load(): faiss_store.py:40-111)."""
@@ -121,8 +137,15 @@ class FAISSStore:
                 # the embedder's result never left HBM: the search is enqueued behind it on its stream and only
                 # ids and scores come back (a sharded deployment ships host bytes in its request message)
                 if self._sharded is None and embeddings.device == self._index.device:
-                    res = self._index.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, embeddings.stream)
-                    embeddings.settled()  # the call has waited for the stream
+                    stream = embeddings.stream
+                    if self._search_share():
+                        # the search runs on the index's share of the chip, behind the point the embedder's stream has
+                        # reached: the embedder's next batch can run beside it (settings.encoder_cus)
+                        from ..flat_index import stream_wait
+                        stream_wait(self._index.device, self._share_stream, embeddings.stream)
+                        stream = self._share_stream
+                    res = self._index.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, stream)
+                    embeddings.settled()  # the call has waited for the stream (and, through it, the embedder's)
                     if embeddings.valid():
                         return res
                     # the encoder's pass left fp16's range (device_embeddings.py): the host path repeats it exactly
@@ -171,8 +194,14 @@ class FAISSStore:
             if self._sharded is not None:
                 self._sharded.shutdown()
                 self._sharded = None
+            dev = self._index.device if self._index is not None else 0
             if self._index is not None:
                 self._index.close()
+            if self._share_stream:
+                from ..flat_index import destroy_stream
+                destroy_stream(dev, self._share_stream)
+                self._share_stream = 0
+            self._share_checked = False
             self._index = None
             self._is_loaded = False
             gc.collect()

@@ -76,6 +76,12 @@ class PipelineSettings(BaseModel):
     # generation (gc.freeze): a full collection over a process that has imported torch / transformers / pydantic walks
     # ~10^6 objects and takes 40-60 ms — one batch in ten of a top-100 rerank profile took 65 ms instead of 20.
     gc_freeze_after_warmup: bool = Field(default=True, alias="RAG_AMD_GC_FREEZE")
+    # A share of the GPU for the query encoder (0 = off; multiples of 32: one CU of every shader engine of every XCD):
+    # its stream owns that many compute units and the index's search stream the rest, so that the encoder of one
+    # batch runs BESIDE the corpus scan of the batch before it when the scheduler has two batches in flight
+    # (include/rag_amd.h rag_stream_create_masked).  Single-GPU deployments; worth it when the scan takes longer than
+    # the encoder (10M-row corpora: 32 with the one-pass scan, 64 with the two-stage search).
+    encoder_cus: int = Field(default=0, alias="RAG_AMD_ENCODER_CUS")
 
     @classmethod
     def from_env(cls, env: dict[str, str] | None = None, **overrides: Any) -> "PipelineSettings":

@@ -1002,6 +1002,26 @@ extern "C" int rag_stream_destroy(int32_t device, void* stream) {
     return RAG_OK;
 }
 
+extern "C" int rag_stream_wait(int32_t device, void* waiter, void* signaler) {
+    RagcDeviceGuard g(device);
+    if (!g.ok) return fail(RAG_ERR_HIP, "hipSetDevice(%d) failed", device);
+    hipEvent_t ev = nullptr;
+    RAGC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaler);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);   // (released once the recorded point has passed)
+    if (e != hipSuccess) return fail(RAG_ERR_HIP, "stream wait failed: %s", hipGetErrorString(e));
+    return RAG_OK;
+}
+
+extern "C" int rag_device_cu_count(int32_t device, int32_t* n_cus) {
+    if (!n_cus) return fail(RAG_ERR_INVALID_ARG, "n_cus is null");
+    hipDeviceProp_t prop;
+    RAGC_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    *n_cus = prop.multiProcessorCount;
+    return RAG_OK;
+}
+
 extern "C" int rag_index_set_cu_budget(rag_index* h, int32_t n_cus) {
     if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
     hipDeviceProp_t prop;

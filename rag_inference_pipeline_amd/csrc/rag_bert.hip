@@ -55,7 +55,8 @@ struct rag_bert {
     bool force_x6 = false;            // this forward pass runs its big-batch GEMMs on the split-bf16 images
     bool background = false;          // rag_bert_set_background
     long long range_events = 0;       // forward passes repeated on the split-bf16 path
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // the handle's own stream
+    hipStream_t user_stream = nullptr;    // rag_bert_set_stream: the caller's stream for the host-ids entry points (not owned)
     std::mutex mu;
     // activation workspace, sized for ws_tokens tokens / ws_seqs sequences
     long long ws_tokens = 0, ws_seqs = 0;
@@ -953,7 +954,7 @@ extern "C" int rag_bert_forward_to_device(rag_bert* h, const int32_t* ids, const
     const int T = cu_seqlens[nseq];
     RagcDeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
-    hipStream_t st = h->stream;
+    hipStream_t st = h->user_stream ? h->user_stream : h->stream;
     // small batches (the query encoder): one graph replay instead of ~45-90 launches
     rc = forward_to_device_graph(h, ids, type_ids, cu_seqlens, nseq, T, max_len, out_kind, normalize, out_dev,
                                  range_flag ? range_flag : h->range_pin, st);
@@ -1009,7 +1010,8 @@ extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* 
     std::lock_guard<std::mutex> lk(h->mu);
     // the id / cu buffers below are also the asynchronous entry point's: nothing of its may still be in flight
     // when they are (re)allocated or overwritten from pageable memory
-    RAGC_HIP_TRY(hipStreamSynchronize(h->stream));
+    hipStream_t st = h->user_stream ? h->user_stream : h->stream;
+    RAGC_HIP_TRY(hipStreamSynchronize(st));
     rc = grow(&h->ids_dev, &h->ids_cap, (long long)T);
     if (rc) return rc;
     if (type_ids) {
@@ -1021,7 +1023,6 @@ extern "C" int rag_bert_forward(rag_bert* h, const int32_t* ids, const int32_t* 
     const size_t n_out = out_elems(h->cfg, out_kind, nseq, T);
     rc = grow(&h->out_dev, &h->out_cap, (long long)n_out);
     if (rc) return rc;
-    hipStream_t st = h->stream;
     RAGC_HIP_TRY(hipMemcpyAsync(h->ids_dev, ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
     if (type_ids) RAGC_HIP_TRY(hipMemcpyAsync(h->types_dev, type_ids, (size_t)T * sizeof(int), hipMemcpyHostToDevice, st));
     RAGC_HIP_TRY(hipMemcpyAsync(h->cu_dev, cu_seqlens, (size_t)(nseq + 1) * sizeof(int), hipMemcpyHostToDevice, st));
@@ -1053,6 +1054,20 @@ extern "C" int rag_bert_set_background(rag_bert* h, int32_t on) {
     if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
     std::lock_guard<std::mutex> lk(h->mu);
     h->background = on != 0;
+    return RAG_OK;
+}
+
+extern "C" int rag_bert_set_stream(rag_bert* h, void* stream) {
+    if (!h) return ragc_fail(RAG_ERR_INVALID_ARG, "null model handle");
+    RagcDeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    // nothing enqueued on the stream that is being left may still be running on the shared buffers
+    RAGC_HIP_TRY(hipStreamSynchronize(h->user_stream ? h->user_stream : h->stream));
+    if (!h->graphs.empty()) {   // (graphs replay on any stream, but their capture stream is gone: rebuild on the new one)
+        for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
+        h->graphs.clear();
+    }
+    h->user_stream = (hipStream_t)stream;
     return RAG_OK;
 }
 

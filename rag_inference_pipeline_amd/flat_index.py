@@ -200,3 +200,14 @@ def create_masked_stream(device: int, first_cu: int, n_cus: int) -> int:
 
 def destroy_stream(device: int, stream: int) -> None:
     _native.check(_native.lib().rag_stream_destroy(int(device), C.c_void_p(int(stream))))
+
+
+def stream_wait(device: int, waiter: int, signaler: int) -> None:
+    """Work enqueued on `waiter` from now on starts when what is on `signaler` now has finished (rag_stream_wait)."""
+    _native.check(_native.lib().rag_stream_wait(int(device), C.c_void_p(int(waiter)), C.c_void_p(int(signaler))))
+
+
+def device_cu_count(device: int) -> int:
+    n = C.c_int32(0)
+    _native.check(_native.lib().rag_device_cu_count(int(device), C.byref(n)))
+    return int(n.value)

@@ -28,6 +28,10 @@ ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--batches", type=int, default=10)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--profile", action="store_true", help="cProfile one batch and print the top host functions")
+ap.add_argument("--dim", type=int, default=384, help="index width; 768 switches the embedder to the bge-base architecture")
+ap.add_argument("--threads", type=int, default=1, help="batches in flight (the scheduler runs batches concurrently)")
+ap.add_argument("--encoder-cus", type=int, default=0, help="RAG_AMD_ENCODER_CUS: the encoder's share of the chip (0 = off)")
+ap.add_argument("--one-pass", action="store_true", help="RAG_AMD_TWO_STAGE=false: the one-pass fp32 scan")
 ap.add_argument("--no-gc", action="store_true", help="run the timed batches with the cyclic garbage collector off (diagnosis)")
 ap.add_argument("--per-batch", action="store_true", help="print every timed batch's wall time")
 a = ap.parse_args()
@@ -50,9 +54,11 @@ con.commit(); con.close()
 print(f"sqlite: {a.rows} docs in {time.time() - t0:.1f}s", flush=True)
 
 settings = PipelineSettings(DOCUMENTS_DIR=os.path.join(tmp, "documents"), DOCUMENTS_PAYLOAD_MODE="full",
-                            DISABLE_CACHE_FOR_PROFILING="true", faiss_dim=384, retrieval_k=a.k,
-                            embedding_model_name="synthetic:all-MiniLM-L6-v2", reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2",
-                            RAG_AMD_RERANKER_DTYPE=a.dtype)
+                            DISABLE_CACHE_FOR_PROFILING="true", faiss_dim=a.dim, retrieval_k=a.k,
+                            embedding_model_name="synthetic:bge-base-en-v1.5" if a.dim == 768 else "synthetic:all-MiniLM-L6-v2",
+                            reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2",
+                            RAG_AMD_RERANKER_DTYPE=a.dtype, RAG_AMD_ENCODER_CUS=a.encoder_cus,
+                            RAG_AMD_TWO_STAGE="false" if a.one_pass else "true")
 
 
 class SyntheticStore(FAISSStore):  # the product's FAISSStore (its search(), two-stage default, device hand-off) over a
@@ -65,7 +71,7 @@ class SyntheticStore(FAISSStore):  # the product's FAISSStore (its search(), two
 
 reg = ComponentRegistry()
 emb = EmbeddingGenerator(settings); reg.register("embedding_generator", emb, emb.load)
-reg.register("faiss_store", SyntheticStore(settings, a.rows, 384))
+reg.register("faiss_store", SyntheticStore(settings, a.rows, a.dim))
 reg.register("document_store", DocumentStore(settings))
 if a.rerank:
     rr = Reranker(settings); reg.register("reranker", rr, rr.load)
@@ -79,15 +85,25 @@ if a.no_gc:
     import gc
     gc.collect(); gc.disable()
 per = []
-t0 = time.perf_counter()
-for _ in range(a.batches):
-    t1 = time.perf_counter()
-    items = ex._process_batch_sync(mk())
-    per.append(time.perf_counter() - t1)
-el = time.perf_counter() - t0
+if a.threads > 1:   # several batches in flight, as the scheduler runs them (batch_scheduler.py:286-288)
+    from concurrent.futures import ThreadPoolExecutor
+    ex._process_batch_sync(mk())
+    with ThreadPoolExecutor(max_workers=a.threads) as pool:
+        t0 = time.perf_counter()
+        futs = [pool.submit(ex._process_batch_sync, mk()) for _ in range(a.batches)]
+        items = [f.result() for f in futs][-1]
+        el = time.perf_counter() - t0
+else:
+    t0 = time.perf_counter()
+    for _ in range(a.batches):
+        t1 = time.perf_counter()
+        items = ex._process_batch_sync(mk())
+        per.append(time.perf_counter() - t1)
+    el = time.perf_counter() - t0
 if a.per_batch:
     print("   per batch (ms):", " ".join(f"{x * 1e3:.1f}" for x in per))
-print(f"rows={a.rows} k={a.k} rerank={a.rerank} dtype={a.dtype}: {el / a.batches * 1e3:.2f} ms/batch  {32 * a.batches / el:.0f} queries/s")
+print(f"rows={a.rows} dim={a.dim} k={a.k} rerank={a.rerank} dtype={a.dtype} threads={a.threads} encoder_cus={a.encoder_cus}"
+      f"{' one-pass' if a.one_pass else ''}: {el / a.batches * 1e3:.2f} ms/batch  {32 * a.batches / el:.0f} queries/s")
 snap = stage_timers.snapshot()
 acc = 0.0
 for s, v in snap.items():

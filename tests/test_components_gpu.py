@@ -408,3 +408,47 @@ def test_a_share_of_the_chip_for_each_stage_changes_no_result(gpu_required):
         idx.close()
     with pytest.raises(RuntimeError):
         create_masked_stream(0, total - 8, 16)      # outside the device
+
+
+def test_encoder_share_of_the_chip_in_the_product_path(gpu_required, tmp_path):
+    """settings.encoder_cus (RAG_AMD_ENCODER_CUS): the embedder's passes run on a stream that owns 32 CUs, searches that
+    follow them on the device on a stream that owns the rest; two batches in flight on pool threads.  Same documents,
+    scores to fp32 rounding (the CU budget may change a split-K choice in the encoder), as the default deployment."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from rag_inference_pipeline_amd.batch_scheduler import Batch
+    from rag_inference_pipeline_amd.schemas import PendingRequest
+    from rag_inference_pipeline_amd.component_registry import ComponentRegistry
+    from rag_inference_pipeline_amd.components.embedding import EmbeddingGenerator
+    from rag_inference_pipeline_amd.flat_index import FlatIndex, SCREEN_FP16
+
+    if torch.cuda.get_device_properties(0).multi_processor_count < 64:
+        pytest.skip("needs a device with at least 64 compute units")
+
+    def build(share):
+        settings = PipelineSettings(DISABLE_CACHE_FOR_PROFILING="true", faiss_dim=384, retrieval_k=10,
+                                    embedding_model_name="synthetic:all-MiniLM-L6-v2:3", RAG_AMD_ENCODER_CUS=share)
+        store = FAISSStore(settings)
+        idx = FlatIndex(384); idx.add_synthetic(200_000, 11); idx.set_screening(SCREEN_FP16)
+        store._index, store._ntotal, store._is_loaded = idx, 200_000, True
+        reg = ComponentRegistry()
+        emb = EmbeddingGenerator(settings); reg.register("embedding_generator", emb, emb.load)
+        reg.register("faiss_store", store)
+        return RetrievalExecutor(reg, settings), emb, store
+
+    rng = np.random.default_rng(5)
+    words = "vector index query document embedding transformer attention memory kernel latency shard merge score".split()
+    batches = [[" ".join(rng.choice(words, size=int(rng.integers(5, 14)))) for _ in range(32)] for _ in range(6)]
+    mk = lambda qs, b: Batch(b, [PendingRequest(request_id=f"b{b}r{i}", query=q, timestamp=0.0) for i, q in enumerate(qs)])
+    ex0, emb0, store0 = build(0)
+    want = [ex0._process_batch_sync(mk(qs, b)) for b, qs in enumerate(batches)]
+    ex1, emb1, store1 = build(32)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        got = list(pool.map(lambda a: ex1._process_batch_sync(mk(a[1], a[0])), enumerate(batches)))
+    assert emb1._share_stream and store1._share_stream          # both streams exist: the partition was really used
+    for wb, gb in zip(want, got):
+        for w, g in zip(wb, gb):
+            assert [d.doc_id for d in g.docs] == [d.doc_id for d in w.docs]
+            np.testing.assert_allclose([d.score for d in g.docs], [d.score for d in w.docs], atol=2e-6)
+    for e, s in ((emb0, store0), (emb1, store1)):
+        e.unload(); s.unload()
