@@ -20,6 +20,7 @@ constexpr int kEmbEntries = 5;
 constexpr int kGraphTokens = 1024;   // a graphed pass holds at most this many (padded) tokens: the small-batch kernels' range
 constexpr int kGraphSeqs = 72;       // ... and this many (padded) sequences
 constexpr int kGraphCache = 24;      // instantiated graphs kept per model (least recently used goes)
+constexpr int kGraphCellsAt = 2 * kGraphTokens + (kGraphSeqs + 1 + 1) / 2 * 2;   // ints: the 8-byte cells start 8-byte aligned
 
 int weight_count(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
 
@@ -90,7 +91,7 @@ struct rag_bert {
     unsigned long long graph_clock = 0;
     bool use_graphs = true;           // RAG_AMD_ENCODER_GRAPH=0 turns the path off
     bool in_capture = false;          // forward_locked is being captured: no event traffic, no reallocation
-    int* g_pin = nullptr;             // pinned: [ids kGraphTokens | types kGraphTokens | cu kGraphSeqs + 1 | cells 8 ints]
+    int* g_pin = nullptr;             // pinned: [ids kGraphTokens | types kGraphTokens | cu kGraphSeqs + 1 (+ pad) | cells 8 ints]
     int *g_ids = nullptr, *g_types = nullptr, *g_cu = nullptr;
     unsigned long long* g_cells = nullptr;   // device copy of the cells: out pointer, flag pointer, float count
     float* g_out = nullptr;           // [kGraphSeqs][hidden]
@@ -667,7 +668,7 @@ __global__ void graph_epilogue_kernel(const float* src, const unsigned long long
 
 int ensure_graph_buffers(rag_bert* h) {
     if (h->g_pin) return RAG_OK;
-    const size_t pin_ints = (size_t)2 * kGraphTokens + kGraphSeqs + 1 + 8;
+    const size_t pin_ints = (size_t)kGraphCellsAt + 8;
     RAGC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->g_pin), pin_ints * sizeof(int), hipHostMallocDefault));
     RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_ids), kGraphTokens * sizeof(int)));
     RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_types), kGraphTokens * sizeof(int)));
@@ -684,7 +685,7 @@ int graph_body(rag_bert* h, int nseq_pad, int T_pad, int maxlen_b, int out_kind,
     int* pin_ids = h->g_pin;
     int* pin_types = h->g_pin + kGraphTokens;
     int* pin_cu = h->g_pin + 2 * kGraphTokens;
-    int* pin_cells = h->g_pin + 2 * kGraphTokens + kGraphSeqs + 1;
+    int* pin_cells = h->g_pin + kGraphCellsAt;
     RAGC_HIP_TRY(hipMemcpyAsync(h->g_ids, pin_ids, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
     RAGC_HIP_TRY(hipMemcpyAsync(h->g_types, pin_types, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
     RAGC_HIP_TRY(hipMemcpyAsync(h->g_cu, pin_cu, (size_t)(nseq_pad + 1) * sizeof(int), hipMemcpyHostToDevice, st));
@@ -764,7 +765,7 @@ int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type
     int* pin_ids = h->g_pin;
     int* pin_types = h->g_pin + kGraphTokens;
     int* pin_cu = h->g_pin + 2 * kGraphTokens;
-    unsigned long long* pin_cells = reinterpret_cast<unsigned long long*>(h->g_pin + 2 * kGraphTokens + kGraphSeqs + 1);
+    unsigned long long* pin_cells = reinterpret_cast<unsigned long long*>(h->g_pin + kGraphCellsAt);
     std::memcpy(pin_ids, ids, (size_t)T * sizeof(int));
     std::memset(pin_ids + T, 0, (size_t)extra * sizeof(int));
     if (type_ids) std::memcpy(pin_types, type_ids, (size_t)T * sizeof(int));
@@ -782,7 +783,11 @@ int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type
     pin_cells[2] = (unsigned long long)nseq * h->cfg.hidden;
     hipGraphExec_t exec = nullptr;
     rc = get_graph(h, nseq_pad, T_pad, maxlen_b, out_kind, normalize, st, &exec);
-    if (rc) return rc;
+    if (rc) {   // a runtime that cannot capture this (rag_last_error says why): the eager path serves, from now on
+        h->use_graphs = false;
+        (void)hipGetLastError();
+        return kNotGraphed;
+    }
     if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
     RAGC_HIP_TRY(hipGraphLaunch(exec, st));
     if (hipEventRecord(h->ws_event, st) == hipSuccess) {
