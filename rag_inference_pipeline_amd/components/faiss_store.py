@@ -21,6 +21,7 @@ multi-device path).
 from __future__ import annotations
 
 import gc
+import threading
 import logging
 from pathlib import Path
 
@@ -50,19 +51,22 @@ class FAISSStore:
         self._is_loaded = False
         self._share_stream = 0     # the search stream of a partitioned chip (settings.encoder_cus), made at first use
         self._share_checked = False
+        self._share_lock = threading.Lock()
 
     def _search_share(self) -> int:
         """settings.encoder_cus > 0 on one GPU: searches that follow the embedder on the device run on a stream that owns
         the CUs the encoder's stream does not, and the index plans its launches for that many (0: no partition)."""
         if not self._share_checked:
-            self._share_checked = True
-            share = int(getattr(self.settings, "encoder_cus", 0) or 0)
-            if share > 0 and self._sharded is None and self._index is not None:
-                from ..flat_index import create_masked_stream, device_cu_count
-                total = device_cu_count(self._index.device)
-                if 0 < share < total:
-                    self._share_stream = create_masked_stream(self._index.device, share, total - share)
-                    self._index.set_cu_budget(total - share)
+            with self._share_lock:   # (batches run on pool threads: the first two may arrive together)
+                if not self._share_checked:
+                    share = int(getattr(self.settings, "encoder_cus", 0) or 0)
+                    if share > 0 and self._sharded is None and self._index is not None:
+                        from ..flat_index import create_masked_stream, device_cu_count
+                        total = device_cu_count(self._index.device)
+                        if 0 < share < total:
+                            self._share_stream = create_masked_stream(self._index.device, share, total - share)
+                            self._index.set_cu_budget(total - share)
+                    self._share_checked = True
         return self._share_stream
 
     def load(self) -> None:
