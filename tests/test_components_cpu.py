@@ -218,3 +218,42 @@ def test_native_pair_encoder_equals_the_python_stand_in_tokenizer():
                 np.testing.assert_array_equal(g, w)
             assert tok.encode_pairs_packed(first, second, max_len, False)[1] is None
     assert HashTokenizer(30522).encode_pairs_packed(["café"], ["x"], 16) is None
+
+
+def test_search_share_of_the_chip_is_set_up_once_and_only_on_one_gpu(monkeypatch):
+    """settings.encoder_cus (RAG_AMD_ENCODER_CUS): FAISSStore creates its search stream over the CUs the encoder does not
+    own at the first device hand-off, once, tells the index how many CUs to plan for, and releases the stream at unload;
+    nothing happens when the setting is off, when it is not smaller than the device, or in a sharded deployment."""
+    from rag_inference_pipeline_amd import flat_index
+    from rag_inference_pipeline_amd.components.faiss_store import FAISSStore
+
+    made, destroyed = [], []
+    monkeypatch.setattr(flat_index, "create_masked_stream", lambda dev, first, n: made.append((dev, first, n)) or 4242)
+    monkeypatch.setattr(flat_index, "destroy_stream", lambda dev, st: destroyed.append((dev, st)))
+    monkeypatch.setattr(flat_index, "device_cu_count", lambda dev: 256)
+
+    class Index:
+        device = 3
+        budget = None
+        closed = False
+        def set_cu_budget(self, n): self.budget = n
+        def close(self): self.closed = True
+
+    def store(**env):
+        s = FAISSStore(PipelineSettings(**env))
+        s._index, s._ntotal, s._is_loaded = Index(), 10, True
+        return s
+
+    s = store(RAG_AMD_ENCODER_CUS=64)
+    assert s._search_share() == 4242 and s._search_share() == 4242
+    assert made == [(3, 64, 192)] and s._index.budget == 192          # once; the CUs after the encoder's 64
+    idx = s._index
+    s.unload()
+    assert destroyed == [(3, 4242)] and idx.closed and s._share_stream == 0
+    for env in ({}, {"RAG_AMD_ENCODER_CUS": 0}, {"RAG_AMD_ENCODER_CUS": 256}):
+        s = store(**env)
+        assert s._search_share() == 0 and s._index.budget is None
+    s = store(RAG_AMD_ENCODER_CUS=64)
+    s._sharded = object()                                              # one process per GPU: the ranks do not partition
+    assert s._search_share() == 0
+    assert made == [(3, 64, 192)]
