@@ -321,271 +321,284 @@ def main() -> None:
     # in front — token ids resident in HBM -> bge-base-architecture encoder (fp32 MFMA, seeded random
     # weights: no checkpoint exists offline) -> CLS pooling + L2 norm -> scan + top-k.  Every rank
     # encodes the 32 queries itself (cheaper than a broadcast of the embeddings).
+    legs_failed: dict[str, str] = {}
     enc_leg = None
     model = None
     enc_step = None
-    if not args.no_encoder_leg and d == 768:
-        from rag_inference_pipeline_amd import _native
-        from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
+    try:
+        if not args.no_encoder_leg and d == 768:
+            from rag_inference_pipeline_amd import _native
+            from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
 
-        ecfg = BertConfig.bge_base()
-        model = BertModel(ecfg, random_weights(ecfg, 0), device=dev)
-        rng = np.random.default_rng(4321)
-        lens = rng.integers(8, 21, size=B)
-        seqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in lens]
-        ids_np, _, cu_np = pack_sequences(seqs)
-        ids_t, cu_t = torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda()
-        Qe2 = [torch.empty((B, d), dtype=torch.float32, device="cuda") for _ in range(3)]
-        enc_n = [0]
+            ecfg = BertConfig.bge_base()
+            model = BertModel(ecfg, random_weights(ecfg, 0), device=dev)
+            rng = np.random.default_rng(4321)
+            lens = rng.integers(8, 21, size=B)
+            seqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in lens]
+            ids_np, _, cu_np = pack_sequences(seqs)
+            ids_t, cu_t = torch.from_numpy(ids_np).cuda(), torch.from_numpy(cu_np).cuda()
+            Qe2 = [torch.empty((B, d), dtype=torch.float32, device="cuda") for _ in range(3)]
+            enc_n = [0]
 
-        def enc_step() -> None:
-            Qe = Qe2[enc_n[0] % 3]   # a batch's embeddings stay put until that batch has been collected
-            enc_n[0] += 1
-            model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
-                                 _native.BERT_OUT_CLS, True, Qe.data_ptr(), sptr)
-            if sharded is None:
-                index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
-            else:
-                submit(Qe)
-
-        # The same step PIPELINED: the encoder of batch i runs on a side stream, under the scan of batch i - 1 (the
-        # product allows it: separate handles, the scheduler runs batches concurrently, batch_scheduler.py:286-288).
-        # Three embedding buffers; a buffer is rewritten only after the search that read it has passed.
-        side = torch.cuda.Stream()
-        ev_enc = [torch.cuda.Event() for _ in range(3)]
-        ev_srch = [torch.cuda.Event() for _ in range(3)]
-        pipe_n = [0]
-
-        def enc_pipe_step() -> None:
-            n = pipe_n[0]
-            pipe_n[0] += 1
-            Qe = Qe2[n % 3]
-            main = torch.cuda.current_stream()
-            if n >= 3:
-                side.wait_event(ev_srch[n % 3])
-            model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
-                                 _native.BERT_OUT_CLS, True, Qe.data_ptr(), side.cuda_stream)
-            ev_enc[n % 3].record(side)
-            main.wait_event(ev_enc[n % 3])
-            if sharded is None:
-                index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
-            else:
-                submit(Qe)
-            ev_srch[n % 3].record(main)
-
-        def timed_loop(fn) -> float:
-            for _ in range(max(2, args.warmup)):
-                fn()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fn()
-            barrier()
-            el = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            return el
-
-        el = timed_loop(enc_step)
-        model.set_background(True)    # kernels that fit beside the scan's resident workgroups (include/rag_amd.h)
-        el_p = timed_loop(enc_pipe_step)
-        model.set_background(False)
-        pipelined = {"value": B * args.steps / el_p, "unit": "queries/s", "ms_per_step": el_p / args.steps * 1e3,
-                     "how": "encoder of batch i on a side stream under the scan of batch i - 1, its small-batch GEMMs in the "
-                            "32-KiB-LDS form that fits beside the scan's resident workgroups (both on all CUs)"}
-        # The same pipeline with the chip PARTITIONED: the encoder's stream owns 32 CUs (one per shader engine), the scan's
-        # stream the other 224 — the scan is HBM-bound and loses 6 %, and the encoder's ~90 short dependent kernels no
-        # longer queue behind the scan's resident workgroups (include/rag_amd.h rag_stream_create_masked).  Shares that
-        # leave the shader engines unequal (16, 24, 40, 48 CUs) DOUBLE the scan's time: workgroups are dealt to engines by
-        # count, an engine with fewer CUs than workgroups runs two persistent workgroups in turn.
-        def run_partitioned(enc_cus: int, time_shared: dict) -> dict:
-            from rag_inference_pipeline_amd.flat_index import create_masked_stream, destroy_stream
-
-            total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            enc_raw = create_masked_stream(dev, 0, enc_cus)
-            scan_raw = create_masked_stream(dev, enc_cus, total_cus - enc_cus)
-            enc_st, scan_st = torch.cuda.ExternalStream(enc_raw), torch.cuda.ExternalStream(scan_raw)
-            part_n = [0]
-
-            def enc_part_step() -> None:
-                n = part_n[0]
-                part_n[0] += 1
-                Qe = Qe2[n % 3]
-                if n >= 3:
-                    enc_st.wait_event(ev_srch[n % 3])
+            def enc_step() -> None:
+                Qe = Qe2[enc_n[0] % 3]   # a batch's embeddings stay put until that batch has been collected
+                enc_n[0] += 1
                 model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
-                                     _native.BERT_OUT_CLS, True, Qe.data_ptr(), enc_raw)
-                ev_enc[n % 3].record(enc_st)
-                scan_st.wait_event(ev_enc[n % 3])
-                index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw)
-                ev_srch[n % 3].record(scan_st)
+                                     _native.BERT_OUT_CLS, True, Qe.data_ptr(), sptr)
+                if sharded is None:
+                    index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
+                else:
+                    submit(Qe)
 
-            model.set_cu_budget(enc_cus)
-            index.set_cu_budget(total_cus - enc_cus)
+            # The same step PIPELINED: the encoder of batch i runs on a side stream, under the scan of batch i - 1 (the
+            # product allows it: separate handles, the scheduler runs batches concurrently, batch_scheduler.py:286-288).
+            # Three embedding buffers; a buffer is rewritten only after the search that read it has passed.
+            side = torch.cuda.Stream()
+            ev_enc = [torch.cuda.Event() for _ in range(3)]
+            ev_srch = [torch.cuda.Event() for _ in range(3)]
+            pipe_n = [0]
 
-            def alone(fn, st) -> float:   # ms per call of one side alone on its share of the chip
-                for _ in range(3):
+            def enc_pipe_step() -> None:
+                n = pipe_n[0]
+                pipe_n[0] += 1
+                Qe = Qe2[n % 3]
+                main = torch.cuda.current_stream()
+                if n >= 3:
+                    side.wait_event(ev_srch[n % 3])
+                model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                     _native.BERT_OUT_CLS, True, Qe.data_ptr(), side.cuda_stream)
+                ev_enc[n % 3].record(side)
+                main.wait_event(ev_enc[n % 3])
+                if sharded is None:
+                    index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), sptr)
+                else:
+                    submit(Qe)
+                ev_srch[n % 3].record(main)
+
+            def timed_loop(fn) -> float:
+                for _ in range(max(2, args.warmup)):
                     fn()
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(st)
-                for _ in range(10):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
                     fn()
-                e1.record(st)
+                barrier()
+                el = time.perf_counter() - t0
+                if dist is not None:
+                    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    el = float(t.item())
+                return el
+
+            el = timed_loop(enc_step)
+            model.set_background(True)    # kernels that fit beside the scan's resident workgroups (include/rag_amd.h)
+            el_p = timed_loop(enc_pipe_step)
+            model.set_background(False)
+            pipelined = {"value": B * args.steps / el_p, "unit": "queries/s", "ms_per_step": el_p / args.steps * 1e3,
+                         "how": "encoder of batch i on a side stream under the scan of batch i - 1, its small-batch GEMMs in the "
+                                "32-KiB-LDS form that fits beside the scan's resident workgroups (both on all CUs)"}
+            # The same pipeline with the chip PARTITIONED: the encoder's stream owns 32 CUs (one per shader engine), the scan's
+            # stream the other 224 — the scan is HBM-bound and loses 6 %, and the encoder's ~90 short dependent kernels no
+            # longer queue behind the scan's resident workgroups (include/rag_amd.h rag_stream_create_masked).  Shares that
+            # leave the shader engines unequal (16, 24, 40, 48 CUs) DOUBLE the scan's time: workgroups are dealt to engines by
+            # count, an engine with fewer CUs than workgroups runs two persistent workgroups in turn.
+            def run_partitioned(enc_cus: int, time_shared: dict) -> dict:
+                from rag_inference_pipeline_amd.flat_index import create_masked_stream, destroy_stream
+
+                total_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+                enc_raw = create_masked_stream(dev, 0, enc_cus)
+                scan_raw = create_masked_stream(dev, enc_cus, total_cus - enc_cus)
+                enc_st, scan_st = torch.cuda.ExternalStream(enc_raw), torch.cuda.ExternalStream(scan_raw)
+                part_n = [0]
+
+                def enc_part_step() -> None:
+                    n = part_n[0]
+                    part_n[0] += 1
+                    Qe = Qe2[n % 3]
+                    if n >= 3:
+                        enc_st.wait_event(ev_srch[n % 3])
+                    model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                         _native.BERT_OUT_CLS, True, Qe.data_ptr(), enc_raw)
+                    ev_enc[n % 3].record(enc_st)
+                    scan_st.wait_event(ev_enc[n % 3])
+                    index.search_device(Qe.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw)
+                    ev_srch[n % 3].record(scan_st)
+
+                model.set_cu_budget(enc_cus)
+                index.set_cu_budget(total_cus - enc_cus)
+
+                def alone(fn, st) -> float:   # ms per call of one side alone on its share of the chip
+                    for _ in range(3):
+                        fn()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    for _ in range(10):
+                        fn()
+                    e1.record(st)
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / 10
+
+                enc_alone = alone(lambda: model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                                               _native.BERT_OUT_CLS, True, Qe2[0].data_ptr(), enc_raw), enc_st)
+                scan_alone = alone(lambda: index.search_device(Qe2[0].data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw), scan_st)
+                el_q = timed_loop(enc_part_step)
                 torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / 10
+                ids_part = out_i.cpu().numpy().copy()
+                model.set_cu_budget(0)
+                index.set_cu_budget(0)
+                enc_step()
+                torch.cuda.synchronize()
+                same = bool(np.array_equal(ids_part, out_i.cpu().numpy()))
+                del enc_st, scan_st
+                destroy_stream(dev, enc_raw)
+                destroy_stream(dev, scan_raw)
+                return {"value": B * args.steps / el_q, "unit": "queries/s", "ms_per_step": el_q / args.steps * 1e3,
+                             "how": f"encoder of batch i on a stream that owns {enc_cus} CUs ({enc_cus // 8} per XCD), scan of batch i - 1 on "
+                                    f"a stream that owns the other {total_cus - enc_cus} (rag_stream_create_masked, rag_*_set_cu_budget)",
+                             "encoder_cus": enc_cus, "encoder_alone_ms_on_its_cus": enc_alone, "scan_alone_ms_on_its_cus": scan_alone,
+                             "identical_to_sequential": same, "time_shared_cus": time_shared}
 
-            enc_alone = alone(lambda: model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
-                                                           _native.BERT_OUT_CLS, True, Qe2[0].data_ptr(), enc_raw), enc_st)
-            scan_alone = alone(lambda: index.search_device(Qe2[0].data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(), scan_raw), scan_st)
-            el_q = timed_loop(enc_part_step)
-            torch.cuda.synchronize()
-            ids_part = out_i.cpu().numpy().copy()
-            model.set_cu_budget(0)
-            index.set_cu_budget(0)
-            enc_step()
-            torch.cuda.synchronize()
-            same = bool(np.array_equal(ids_part, out_i.cpu().numpy()))
-            del enc_st, scan_st
-            destroy_stream(dev, enc_raw)
-            destroy_stream(dev, scan_raw)
-            return {"value": B * args.steps / el_q, "unit": "queries/s", "ms_per_step": el_q / args.steps * 1e3,
-                         "how": f"encoder of batch i on a stream that owns {enc_cus} CUs ({enc_cus // 8} per XCD), scan of batch i - 1 on "
-                                f"a stream that owns the other {total_cus - enc_cus} (rag_stream_create_masked, rag_*_set_cu_budget)",
-                         "encoder_cus": enc_cus, "encoder_alone_ms_on_its_cus": enc_alone, "scan_alone_ms_on_its_cus": scan_alone,
-                         "identical_to_sequential": same, "time_shared_cus": time_shared}
-
-        if sharded is None:   # (32: one CU of every shader engine of every XCD)
-            pipelined = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32")), pipelined)
-        enc_leg = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
-                   "tokens_per_batch": int(cu_np[-1]),
-                   "pipelined": pipelined,
-                   "encoder": "bge-base-en-v1.5 architecture (12x768), seeded random weights, CLS pooling + L2 norm, "
-                              "two-plane fp16 GEMMs (fp32 accuracy); token ids resident in HBM"}
+            if sharded is None:   # (32: one CU of every shader engine of every XCD)
+                pipelined = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32")), pipelined)
+            enc_leg = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                       "tokens_per_batch": int(cu_np[-1]),
+                       "pipelined": pipelined,
+                       "encoder": "bge-base-en-v1.5 architecture (12x768), seeded random weights, CLS pooling + L2 norm, "
+                                  "two-plane fp16 GEMMs (fp32 accuracy); token ids resident in HBM"}
+    except Exception as exc:  # noqa: BLE001  (an extra leg must not cost the run its headline line)
+        legs_failed["with_query_encoder"] = f"{type(exc).__name__}: {exc}"
+        enc_leg = None
 
     # Extra leg (never `value`, one GPU only): the stage BASELINE configs[2] puts behind the scan — the cross-encoder
     # over 32 x 100 (query, document) pairs (reference reranker.py:237-272), ms-marco-MiniLM-L-6 architecture with
     # seeded random weights, token ids resident in HBM; in the default fp32-accurate mode and in the fp16 mode the
     # reference itself uses on a GPU (reranker.py:91-93).
     rerank_leg = None
-    if not args.no_rerank_leg and world == 1:
-        from rag_inference_pipeline_amd import _native
-        from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
+    try:
+        if not args.no_rerank_leg and world == 1:
+            from rag_inference_pipeline_amd import _native
+            from rag_inference_pipeline_amd.bert import BertConfig, BertModel, pack_sequences, random_weights
 
-        rng = np.random.default_rng(99)
-        plens = rng.integers(36, 76, size=B * 100)
-        pseqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in plens]
-        pids, ptypes, pcu = pack_sequences(pseqs, [[0] * 10 + [1] * (len(q) - 10) for q in pseqs])
-        pids_t, ptypes_t, pcu_t = (torch.from_numpy(a).cuda() for a in (pids, ptypes, pcu))
-        pout = torch.empty((len(pseqs), 1), dtype=torch.float32, device="cuda")
-        rerank_leg = {"pairs": len(pseqs), "tokens": int(pcu[-1]),
-                      "model": "cross-encoder/ms-marco-MiniLM-L-6-v2 architecture (6 x 384), seeded random weights; "
-                               "token ids resident in HBM, sigmoid scores left in HBM"}
-        for mode, key in (("f32", "default_fp32_accurate"), ("f16", "fp16_mode")):
-            rcfg = BertConfig.ms_marco_minilm_l6()
-            rcfg.gemm_dtype = mode
-            rmodel = BertModel(rcfg, random_weights(rcfg, 0), device=dev)
-            st = torch.cuda.current_stream().cuda_stream
+            rng = np.random.default_rng(99)
+            plens = rng.integers(36, 76, size=B * 100)
+            pseqs = [rng.integers(1000, 30000, size=int(n)).tolist() for n in plens]
+            pids, ptypes, pcu = pack_sequences(pseqs, [[0] * 10 + [1] * (len(q) - 10) for q in pseqs])
+            pids_t, ptypes_t, pcu_t = (torch.from_numpy(a).cuda() for a in (pids, ptypes, pcu))
+            pout = torch.empty((len(pseqs), 1), dtype=torch.float32, device="cuda")
+            rerank_leg = {"pairs": len(pseqs), "tokens": int(pcu[-1]),
+                          "model": "cross-encoder/ms-marco-MiniLM-L-6-v2 architecture (6 x 384), seeded random weights; "
+                                   "token ids resident in HBM, sigmoid scores left in HBM"}
+            for mode, key in (("f32", "default_fp32_accurate"), ("f16", "fp16_mode")):
+                rcfg = BertConfig.ms_marco_minilm_l6()
+                rcfg.gemm_dtype = mode
+                rmodel = BertModel(rcfg, random_weights(rcfg, 0), device=dev)
+                st = torch.cuda.current_stream().cuda_stream
 
-            def rpass():
-                rmodel.forward_device(pids_t.data_ptr(), ptypes_t.data_ptr(), pcu_t.data_ptr(), len(pseqs), int(pcu[-1]),
-                                      int(plens.max()), _native.BERT_OUT_PROBS, False, pout.data_ptr(), st)
-            for _ in range(3):
-                rpass()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                rpass()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            rerank_leg[key] = {"ms_per_batch": ms, "pairs_per_s": len(pseqs) / ms * 1e3,
-                               "score_checksum": float(pout.sum().item())}
-            rmodel.close()
-        rerank_leg["note"] = ("default: GEMMs on the fp16 matrix cores with every fp32 operand as two fp16 planes (fp32 accuracy); "
-                              "fp16_mode (RAG_AMD_RERANKER_DTYPE=f16): fp16 activations stored in MFMA-fragment order, GEMMs and "
-                              "attention on the fp16 matrix cores, fp32 accumulation and statistics")
+                def rpass():
+                    rmodel.forward_device(pids_t.data_ptr(), ptypes_t.data_ptr(), pcu_t.data_ptr(), len(pseqs), int(pcu[-1]),
+                                          int(plens.max()), _native.BERT_OUT_PROBS, False, pout.data_ptr(), st)
+                for _ in range(3):
+                    rpass()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    rpass()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 5
+                rerank_leg[key] = {"ms_per_batch": ms, "pairs_per_s": len(pseqs) / ms * 1e3,
+                                   "score_checksum": float(pout.sum().item())}
+                rmodel.close()
+            rerank_leg["note"] = ("default: GEMMs on the fp16 matrix cores with every fp32 operand as two fp16 planes (fp32 accuracy); "
+                                  "fp16_mode (RAG_AMD_RERANKER_DTYPE=f16): fp16 activations stored in MFMA-fragment order, GEMMs and "
+                                  "attention on the fp16 matrix cores, fp32 accumulation and statistics")
+    except Exception as exc:  # noqa: BLE001  (an extra leg must not cost the run its headline line)
+        legs_failed["rerank_stage"] = f"{type(exc).__name__}: {exc}"
+        rerank_leg = None
 
     # Extra leg (never `value`): the same step through the two-stage exact search — fp16 screening scan
     # of a scaled copy of the corpus, canonical fp32 re-scoring of the band, per-query certificate,
     # device-side fp32 fallback (include/rag_amd.h rag_index_set_screening).  Same ids, same score bits.
     two_leg = None
-    if not args.no_two_stage_leg and d <= 1024 and k <= 100:
-        from rag_inference_pipeline_amd.flat_index import SCREEN_FP16
+    try:
+        if not args.no_two_stage_leg and d <= 1024 and k <= 100:
+            from rag_inference_pipeline_amd.flat_index import SCREEN_FP16
 
-        index.set_screening(SCREEN_FP16)
-        if index.screening == SCREEN_FP16:
-            for _ in range(max(2, args.warmup)):
-                step()
-            barrier()
-            index.screen_stats(reset=True)
-            index.profile_enable(True)
-            index.profile(reset=True)
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            barrier()
-            el = time.perf_counter() - t0
-            s1_ms_total, s1_launches = index.profile(reset=True)
-            index.profile_enable(False)
-            if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            lat2 = []
-            for _ in range(args.latency_steps):
+            index.set_screening(SCREEN_FP16)
+            if index.screening == SCREEN_FP16:
+                for _ in range(max(2, args.warmup)):
+                    step()
                 barrier()
-                t1 = time.perf_counter()
-                step()
-                torch.cuda.synchronize()
-                lat2.append(time.perf_counter() - t1)
-            st = index.screen_stats()
-            step(); barrier()
-            r2_s0 = (fin["s"] if world > 1 else out_s).cpu().numpy()
-            r2_i0 = (fin["i"] if world > 1 else out_i).cpu().numpy()
-            host_two_stage = host_leg()
-            if host_two_stage is not None and "_I" in host_two_stage:
-                Dh, Ih = host_two_stage.pop("_D"), host_two_stage.pop("_I")
-                host_two_stage["identical_to_device_path"] = bool(np.array_equal(Ih, r2_i0) and
-                                                                  np.array_equal(Dh.view(np.uint32), r2_s0.view(np.uint32)))
-            enc2 = None
-            if enc_step is not None:  # text ids -> encoder -> two-stage search
-                e2 = timed_loop(enc_step)
-                model.set_background(True)
-                e2p = timed_loop(enc_pipe_step)
-                model.set_background(False)
-                pipe2 = {"value": B * args.steps / e2p, "unit": "queries/s", "ms_per_step": e2p / args.steps * 1e3}
-                if sharded is None:   # the two-stage scan is half as long: the encoder gets 64 CUs to stay the shorter side
-                    pipe2 = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS_TWO_STAGE", "64")), pipe2)
-                enc2 = {"value": B * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3, "pipelined": pipe2}
-                step()  # leave the precomputed-embedding results in the output buffers for the comparison below
+                index.screen_stats(reset=True)
+                index.profile_enable(True)
+                index.profile(reset=True)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
                 barrier()
-            r2_s = (fin["s"] if world > 1 else out_s).cpu().numpy()
-            r2_i = (fin["i"] if world > 1 else out_i).cpu().numpy()
-            d64 = (d + 63) // 64 * 64
-            s1_ms = s1_ms_total / max(s1_launches, 1)
-            s1_bytes = 2.0 * n_local * d64
-            two_leg = {
-                "value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
-                "p50_latency_ms": float(np.median(lat2) * 1e3) if lat2 else None,
-                "identical_to_one_pass": bool(np.array_equal(r2_i, res_i) and
-                                              np.array_equal(r2_s.view(np.uint32), res_s.view(np.uint32))),
-                "certificate_fallbacks_rank0": st["fallbacks"], "queries_rank0": st["queries"],
-                "max_observed_error_over_bound": st["max_err_ratio"],
-                "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel<P=1> (fp16 screening pass)",
-                             "achieved": s1_bytes / (s1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": s1_bytes / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_kernel_ms": s1_ms,
-                             "algorithmic_bytes_per_launch": s1_bytes},
-                "note": "fp16 copy of the corpus read once per batch (2*N*d bytes), exact fp32 second stage; "
-                        "+50% index memory",
-            }
-            if enc2 is not None:
-                two_leg["with_query_encoder"] = enc2
-            if host_two_stage is not None:
-                two_leg["host_submit_to_host_results"] = host_two_stage
+                el = time.perf_counter() - t0
+                s1_ms_total, s1_launches = index.profile(reset=True)
+                index.profile_enable(False)
+                if dist is not None:
+                    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    el = float(t.item())
+                lat2 = []
+                for _ in range(args.latency_steps):
+                    barrier()
+                    t1 = time.perf_counter()
+                    step()
+                    torch.cuda.synchronize()
+                    lat2.append(time.perf_counter() - t1)
+                st = index.screen_stats()
+                step(); barrier()
+                r2_s0 = (fin["s"] if world > 1 else out_s).cpu().numpy()
+                r2_i0 = (fin["i"] if world > 1 else out_i).cpu().numpy()
+                host_two_stage = host_leg()
+                if host_two_stage is not None and "_I" in host_two_stage:
+                    Dh, Ih = host_two_stage.pop("_D"), host_two_stage.pop("_I")
+                    host_two_stage["identical_to_device_path"] = bool(np.array_equal(Ih, r2_i0) and
+                                                                      np.array_equal(Dh.view(np.uint32), r2_s0.view(np.uint32)))
+                enc2 = None
+                if enc_step is not None:  # text ids -> encoder -> two-stage search
+                    e2 = timed_loop(enc_step)
+                    model.set_background(True)
+                    e2p = timed_loop(enc_pipe_step)
+                    model.set_background(False)
+                    pipe2 = {"value": B * args.steps / e2p, "unit": "queries/s", "ms_per_step": e2p / args.steps * 1e3}
+                    if sharded is None:   # the two-stage scan is half as long: the encoder gets 64 CUs to stay the shorter side
+                        pipe2 = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS_TWO_STAGE", "64")), pipe2)
+                    enc2 = {"value": B * args.steps / e2, "unit": "queries/s", "ms_per_step": e2 / args.steps * 1e3, "pipelined": pipe2}
+                    step()  # leave the precomputed-embedding results in the output buffers for the comparison below
+                    barrier()
+                r2_s = (fin["s"] if world > 1 else out_s).cpu().numpy()
+                r2_i = (fin["i"] if world > 1 else out_i).cpu().numpy()
+                d64 = (d + 63) // 64 * 64
+                s1_ms = s1_ms_total / max(s1_launches, 1)
+                s1_bytes = 2.0 * n_local * d64
+                two_leg = {
+                    "value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
+                    "p50_latency_ms": float(np.median(lat2) * 1e3) if lat2 else None,
+                    "identical_to_one_pass": bool(np.array_equal(r2_i, res_i) and
+                                                  np.array_equal(r2_s.view(np.uint32), res_s.view(np.uint32))),
+                    "certificate_fallbacks_rank0": st["fallbacks"], "queries_rank0": st["queries"],
+                    "max_observed_error_over_bound": st["max_err_ratio"],
+                    "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel<P=1> (fp16 screening pass)",
+                                 "achieved": s1_bytes / (s1_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": s1_bytes / (s1_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_kernel_ms": s1_ms,
+                                 "algorithmic_bytes_per_launch": s1_bytes},
+                    "note": "fp16 copy of the corpus read once per batch (2*N*d bytes), exact fp32 second stage; "
+                            "+50% index memory",
+                }
+                if enc2 is not None:
+                    two_leg["with_query_encoder"] = enc2
+                if host_two_stage is not None:
+                    two_leg["host_submit_to_host_results"] = host_two_stage
+    except Exception as exc:  # noqa: BLE001  (an extra leg must not cost the run its headline line)
+        legs_failed["two_stage_exact"] = f"{type(exc).__name__}: {exc}"
+        two_leg = None
 
     if model is not None:
         model.close()
@@ -667,6 +680,8 @@ def main() -> None:
             out["two_stage_exact"] = two_leg
         if rerank_leg is not None:
             out["rerank_stage"] = rerank_leg
+        if legs_failed:
+            out["legs_failed"] = legs_failed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         sys.stdout.flush()
