@@ -40,7 +40,10 @@
 extern "C" {
 #endif
 
-#define RAG_AMD_ABI_VERSION 1
+/* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
+ * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
+ * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
+#define RAG_AMD_ABI_VERSION 4
 
 /* status codes */
 #define RAG_OK 0
@@ -59,6 +62,12 @@ extern "C" {
 
 /* ABI version of the loaded library (compare with RAG_AMD_ABI_VERSION). Never fails. */
 int rag_abi_version(void);
+
+/* Digest of the sources this library was compiled from (hex SHA-256 over include/rag_amd.h and every file of csrc/ in
+ * name order, passed in by the build as -DRAG_AMD_SOURCE_DIGEST; "unknown" for a hand build).  The loader refuses — or
+ * rebuilds — a library whose digest differs from the sources beside it: *.so files are not tracked by git but do
+ * travel with a working tree, so "the library is older than its callers" is a state that occurs.  Never fails. */
+const char* rag_source_digest(void);
 
 /* Number of visible HIP devices (0 when there is no GPU / no driver). Never fails. */
 int rag_device_count(void);
@@ -237,6 +246,66 @@ int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t
                                          int64_t scores_offset_bytes, int64_t flag_offset_bytes,
                                          float* out_scores_dev, int64_t* out_ids_dev, uint32_t* any_flag_dev,
                                          void* host_mirror, void* stream);
+
+
+/* ---- C1: the shard step's collectives on an own RCCL communicator (SURVEY §8a "C1", §8e) ------------------- */
+
+/* The reference has no multi-device code (faiss_store.py:37: one index, one process).  With the corpus split over G
+ * GPUs — one process each — a search is: local scan + top-k -> ONE all-gather of every rank's packed [ids | scores |
+ * flag] block -> merge of the G lists on every rank.  These entry points put the collective on the SAME stream as the
+ * kernels around it: torch.distributed (or any launcher) only carries the 128-byte unique id from rank 0 to the other
+ * ranks; it is not on the data path.  RCCL is bound at run time (see csrc/rag_comm.hip for the search order). */
+typedef struct rag_comm rag_comm;
+#define RAG_COMM_ID_BYTES 128
+#define RAG_COMM_HEAD_WORDS 4   /* a request's head: four 64-bit words [op, nq, k, d] (rag_inference_pipeline_amd/sharded.py) */
+
+/* Bind RCCL (NULL: default search order) and report its version code (e.g. 22606); idempotent. */
+int rag_comm_runtime(const char* librccl_path, int32_t* version_out);
+
+/* Rank 0: a fresh unique id (ncclGetUniqueId), to be handed to every rank by the launcher's own means. */
+int rag_comm_unique_id(uint8_t* id_out /* RAG_COMM_ID_BYTES */);
+
+/* Collective: every rank of the group calls it with the same id (ncclCommInitRank on `device`). */
+int rag_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, rag_comm** out);
+int rag_comm_destroy(rag_comm* c);
+int32_t rag_comm_rank(const rag_comm* c);
+int32_t rag_comm_world(const rag_comm* c);
+
+/* ncclAllGather / ncclBroadcast of raw bytes, asynchronous on `stream` (device pointers on the communicator's device;
+ * recv_dev holds world * bytes_per_rank bytes, rank r's block at r * bytes_per_rank). */
+int rag_comm_all_gather_device(rag_comm* c, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
+int rag_comm_broadcast_device(rag_comm* c, void* buf_dev, int64_t bytes, int32_t root, void* stream);
+
+/* One served request = one fixed-size message [RAG_COMM_HEAD_WORDS x int64 head | payload] (the query batch).  On
+ * `root` the message is uploaded from msg_host (pinned; may be NULL when msg_dev already holds it) and broadcast; on
+ * every rank a last, tiny kernel stores the head and then `seq` (> 0, increasing) into head_mirror — pinned host
+ * memory of RAG_COMM_HEAD_WORDS + 1 64-bit words the device can write (may be NULL) — so that a follower learns what to
+ * launch by polling one host word (rag_comm_wait_head) instead of synchronising the stream.  Asynchronous on `stream`;
+ * the queries stay in msg_dev for the search that follows on the same stream. */
+int rag_comm_request_device(rag_comm* c, const void* msg_host, void* msg_dev, int64_t bytes, int32_t root,
+                            void* head_mirror, uint64_t seq, void* stream);
+
+/* Spin (then nap in 50 us steps once 2 ms have passed) until head_mirror's sequence word equals `seq`; copies the
+ * head's RAG_COMM_HEAD_WORDS words to head_out.  timeout_us < 0: wait for ever.  RAG_ERR_STATE on timeout. */
+int rag_comm_wait_head(const void* head_mirror, uint64_t seq, int64_t timeout_us, int64_t* head_out);
+
+/* Byte layout of one rank's packed result block for (nq, k): nq*k int64 ids at 0, nq*k fp32 scores at
+ * *scores_offset, one uint32 "not final" word at *flag_offset, *block_bytes rounded up to a multiple of 8. */
+int rag_pack_layout(int32_t nq, int32_t k, int64_t* scores_offset, int64_t* flag_offset, int64_t* block_bytes);
+
+/* The whole shard step in one call, enqueued on ONE stream:
+ *   rag_index_search_device_ex(h, queries_dev, nq, k, ..., mode, flag) into pack_dev (this rank's block, rag_pack_layout)
+ *   -> ncclAllGather(pack_dev -> gathered_dev: world blocks)
+ *   -> rag_merge_topk_packed_flagged_device(gathered_dev) into out_scores_dev / out_ids_dev / any_flag_dev and, when
+ *      host_mirror is given (pinned, one block's layout), into host memory by the merge kernel itself.
+ * comm_stream (NULL: `stream`) may name a second stream for the all-gather and the merge: they then start when the
+ * local search has finished on `stream` (an event) and run BESIDE the next batch's local search — over xGMI the
+ * collective's latency leaves the step time.  The caller waits for comm_stream (or `stream`) before reading results.
+ * Replaces, for a sharded index, what faiss_store.py:152 does in one process. */
+int rag_index_search_gather_device(rag_index* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k,
+                                   int32_t mode, void* pack_dev, void* gathered_dev, float* out_scores_dev,
+                                   int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror, void* stream,
+                                   void* comm_stream);
 
 /* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
 

@@ -13,6 +13,7 @@ Hugging Face BERT / RoBERTa / XLM-RoBERTa state dicts into it.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import itertools
 import json
 import os
@@ -233,6 +234,7 @@ class BertModel:
         self.cfg = cfg
         self.device = int(device)
         self._lib = _native.lib()
+        self._flag_lock = threading.Lock()
         shapes = cfg.weight_shapes()
         missing = [k for k in shapes if k not in weights]
         if missing:
@@ -312,14 +314,15 @@ class BertModel:
         """(pinned int32 view of one word, its address): a fresh zeroed word of a small ring for one asynchronous pass."""
         import torch
 
-        if getattr(self, "_flag_ring", None) is None:
-            self._flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
-            self._flag_next = 0
-        i = self._flag_next
-        self._flag_next = (i + 1) % 256
-        word = self._flag_ring[i:i + 1]
-        word.zero_()
-        return word, self._flag_ring.data_ptr() + 4 * i
+        with self._flag_lock:   # (batches run on pool threads: two passes must never share a word)
+            if getattr(self, "_flag_ring", None) is None:
+                self._flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+                self._flag_next = 0
+            i = self._flag_next
+            self._flag_next = (i + 1) % 256
+            word = self._flag_ring[i:i + 1]
+            word.zero_()
+            return word, self._flag_ring.data_ptr() + 4 * i
 
     def set_background(self, on: bool = True) -> None:
         """Small-batch GEMMs in their 32-KiB-LDS form, for running the encoder on a side stream under a long-running

@@ -61,7 +61,13 @@ class EmbeddingGenerator:
             self._tokenizer, self._max_len = tokenizer, max_len
             self._share_stream = 0
             share = int(getattr(self.settings, "encoder_cus", 0) or 0)
-            if share > 0 and self._dist_world() == 1:
+            handoff = bool(getattr(self.settings, "disable_cache_for_profiling", True))
+            if share > 0 and not handoff:
+                # with the text cache on, batches go through encode() and the index searches on its own unmasked stream:
+                # a share for the encoder would only slow it down (there is nothing beside it to make room for)
+                logger.warning("RAG_AMD_ENCODER_CUS=%d ignored: the partition serves the device hand-off path, which is "
+                               "active only with DISABLE_CACHE_FOR_PROFILING=true", share)
+            if share > 0 and handoff and self._dist_world() == 1:
                 # the encoder's share of the chip (settings.encoder_cus): its passes run on these CUs only, beside
                 # whatever the index's search stream runs on the others (components/faiss_store.py)
                 from ..flat_index import create_masked_stream

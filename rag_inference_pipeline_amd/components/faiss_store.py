@@ -60,6 +60,9 @@ class FAISSStore:
             with self._share_lock:   # (batches run on pool threads: the first two may arrive together)
                 if not self._share_checked:
                     share = int(getattr(self.settings, "encoder_cus", 0) or 0)
+                    # (only reached from the device hand-off branch of search(): a store that never sees a
+                    # DeviceEmbeddings batch never partitions.  Once it has, host-array searches keep planning for the
+                    # index's share as well — a 6 % slower scan at 224 of 256 CUs — rather than flip the budget per call.)
                     if share > 0 and self._sharded is None and self._index is not None:
                         from ..flat_index import create_masked_stream, device_cu_count
                         total = device_cu_count(self._index.device)

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "flat_kernels.hip.h"
+#include "rag_comm_internal.h"
 #include "rag_common.h"
 
 namespace {
@@ -377,9 +378,10 @@ int setup_dynamic_deal(rag_index* h, ragk::ScanParams& sp, int grid, int waves) 
     const int n_dyn_tiles = sp.n_tiles - tile0;
     const int want_singles = std::min(n_dyn_tiles, grid * std::max(0, h->dyn_singles_per_wg));
     const int n_groups = (n_dyn_tiles - want_singles) / waves;
+    // (the slot is consumed by the caller, once the launch that zeroes the next counter has been enqueued: an error
+    // return between here and there must not leave the next launch on a counter nobody reset)
     sp.dyn_ctr = h->dyn_ctrs + h->dyn_slot % kDynSlots;
     sp.dyn_ctr_next = h->dyn_ctrs + (h->dyn_slot + 1) % kDynSlots;
-    ++h->dyn_slot;
     sp.dyn_tile0 = tile0;
     sp.n_dyn_groups = n_groups;
     sp.n_singles = n_dyn_tiles - n_groups * waves;
@@ -536,6 +538,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
         HIP_TRY(hipGetLastError());
+        if (sp.dyn_ctr) ++h->dyn_slot;
     }
     if (timed) {
         HIP_TRY(hipEventRecord(e1, st));
@@ -684,6 +687,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(waves * 64), lds, st, sp);
     HIP_TRY(hipGetLastError());
+    if (sp.dyn_ctr) ++h->dyn_slot;
     if (h->prof) {
         HIP_TRY(hipEventRecord(e1, st));
         prof_push(h, e0, e1);
@@ -1349,6 +1353,58 @@ extern "C" int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metr
                         reinterpret_cast<const uint32_t*>(base + flag_offset_bytes), shard_stride_bytes / 4, any_flag_dev,
                         hm ? reinterpret_cast<float*>(hm + scores_offset_bytes) : nullptr, reinterpret_cast<long long*>(hm),
                         hm ? reinterpret_cast<uint32_t*>(hm + flag_offset_bytes) : nullptr);
+}
+
+
+// ---- the shard step in one call (C1) ------------------------------------------------------------------
+
+extern "C" int rag_pack_layout(int32_t nq, int32_t k, int64_t* scores_offset, int64_t* flag_offset, int64_t* block_bytes) {
+    if (nq <= 0 || k <= 0) return fail(RAG_ERR_INVALID_ARG, "nq=%d k=%d out of range", nq, k);
+    const int64_t n = (int64_t)nq * k;
+    if (scores_offset) *scores_offset = 8 * n;
+    if (flag_offset) *flag_offset = 12 * n;
+    if (block_bytes) *block_bytes = (12 * n + 4 + 7) / 8 * 8;
+    return RAG_OK;
+}
+
+extern "C" int rag_index_search_gather_device(rag_index* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k,
+                                              int32_t mode, void* pack_dev, void* gathered_dev, float* out_scores_dev,
+                                              int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror,
+                                              void* stream, void* comm_stream) {
+    if (!c) return fail(RAG_ERR_INVALID_ARG, "null communicator");
+    if (nq <= 0) return fail(RAG_ERR_INVALID_ARG, "nq must be positive");
+    if (!pack_dev || !gathered_dev || !any_flag_dev) return fail(RAG_ERR_INVALID_ARG, "null pack / gather / flag buffer");
+    if (reinterpret_cast<uintptr_t>(pack_dev) % 8 || reinterpret_cast<uintptr_t>(gathered_dev) % 8)
+        return fail(RAG_ERR_INVALID_ARG, "packed blocks must be 8-byte aligned");
+    if (mode != RAG_SEARCH_DEFAULT && mode != RAG_SEARCH_EXACT_ONE_PASS && mode != RAG_SEARCH_DEFER_FALLBACK)
+        return fail(RAG_ERR_INVALID_ARG, "unknown search mode %d", mode);
+    int64_t s_off = 0, f_off = 0, blk = 0;
+    int rc = rag_pack_layout(nq, k, &s_off, &f_off, &blk);
+    if (rc) return rc;
+    char* pack = static_cast<char*>(pack_dev);
+    float* pack_s = reinterpret_cast<float*>(pack + s_off);
+    long long* pack_i = reinterpret_cast<long long*>(pack);
+    uint32_t* pack_f = reinterpret_cast<uint32_t*>(pack + f_off);
+    rc = check_search_args(h, queries_dev, nq, k, pack_s, pack_i);
+    if (rc) return rc;
+    if (ragc_comm_device(c) != h->device) return fail(RAG_ERR_INVALID_ARG, "communicator lives on device %d, the index on %d", ragc_comm_device(c), h->device);
+    const int world = ragc_comm_world(c);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t cst = comm_stream ? (hipStream_t)comm_stream : st;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        // the flag word of the block is written in every mode (0: this rank's list is final)
+        rc = search_device_locked(h, queries_dev, nq, k, pack_s, pack_i, st, nullptr, mode, pack_f);
+        if (rc) return rc;
+        if (cst != st) {   // the collective and the merge start when the local search has finished (h->ws_event was just recorded on st)
+            HIP_TRY(hipStreamWaitEvent(cst, h->ws_event, 0));
+        }
+        rc = ragc_comm_all_gather(c, pack_dev, gathered_dev, (size_t)blk, cst);
+        if (rc) return rc;
+    }
+    return rag_merge_topk_packed_flagged_device(h->device, h->metric, world, nq, k, gathered_dev, blk, s_off, f_off, out_scores_dev,
+                                                out_ids_dev, any_flag_dev, host_mirror, (void*)cst);
 }
 
 #ifdef RAGK_STAMPS

@@ -21,6 +21,8 @@ constexpr int kGraphTokens = 1024;   // a graphed pass holds at most this many (
 constexpr int kGraphSeqs = 72;       // ... and this many (padded) sequences
 constexpr int kGraphCache = 24;      // instantiated graphs kept per model (least recently used goes)
 constexpr int kGraphCellsAt = 2 * kGraphTokens + (kGraphSeqs + 1 + 1) / 2 * 2;   // ints: the 8-byte cells start 8-byte aligned
+constexpr int kGraphBlockInts = kGraphCellsAt + 8;
+constexpr int kGraphStages = 2;      // pinned staging blocks that take turns
 
 int weight_count(const rag_bert_config& c) { return kEmbEntries + kPerLayer * c.n_layers + (c.head != RAG_HEAD_NONE ? 4 : 0); }
 
@@ -91,13 +93,20 @@ struct rag_bert {
     unsigned long long graph_clock = 0;
     bool use_graphs = true;           // RAG_AMD_ENCODER_GRAPH=0 turns the path off
     bool in_capture = false;          // forward_locked is being captured: no event traffic, no reallocation
-    int* g_pin = nullptr;             // pinned: [ids kGraphTokens | types kGraphTokens | cu kGraphSeqs + 1 (+ pad) | cells 8 ints]
-    int *g_ids = nullptr, *g_types = nullptr, *g_cu = nullptr;
-    unsigned long long* g_cells = nullptr;   // device copy of the cells: out pointer, flag pointer, float count
+    // One block layout, host and device: [ids kGraphTokens | types kGraphTokens | cu kGraphSeqs + 1 (+ pad) | cells 8 ints].
+    // The upload of a call's block is ONE copy enqueued in front of the replay (outside the graph, so the graph holds no
+    // host address); kGraphStages pinned blocks take turns, each with the event of its last upload, so a call fills its
+    // block while the previous call's pass is still running (round 3 had one block and waited for the whole pass).
+    int* g_pin[kGraphStages] = {};
+    hipEvent_t g_up[kGraphStages] = {};
+    bool g_up_used[kGraphStages] = {};
+    unsigned g_turn = 0;
+    int* g_blk = nullptr;             // device copy of the block (passes on one stream run in order, so one is enough)
+    int *g_ids = nullptr, *g_types = nullptr, *g_cu = nullptr;   // views into g_blk
+    unsigned long long* g_cells = nullptr;   // view: out pointer, flag pointer, float count
     float* g_out = nullptr;           // [kGraphSeqs][hidden]
     uint32_t* g_flag = nullptr;       // the range flag of a graph pass (device memory; published through the cell)
-    hipEvent_t g_done = nullptr;
-    bool g_used = false;
+    unsigned long long ws_generation = 0;    // bumped whenever ensure_ws reallocates: cached graphs hold the old addresses
 };
 
 namespace {
@@ -113,8 +122,19 @@ int grow(T** p, long long* cap, long long want) {
     return RAG_OK;
 }
 
+// Cached encoder graphs hold the workspace's addresses as kernel arguments: once a buffer is reallocated every one of
+// them would replay into freed memory.  Callers have synchronised (nothing is in flight) before ensure_ws reallocates.
+void drop_graphs(rag_bert* h) {
+    for (auto& e : h->graphs) (void)hipGraphExecDestroy(e.exec);
+    h->graphs.clear();
+}
+
 int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
     const rag_bert_config& c = h->cfg;
+    if (tokens > h->ws_tokens || nseq > h->ws_seqs) {
+        drop_graphs(h);
+        ++h->ws_generation;
+    }
     if (tokens > h->ws_tokens) {
         float** bufs[] = {&h->x, &h->y, &h->qkv, &h->ctx, &h->ffn};
         for (float** b : bufs) {
@@ -667,29 +687,34 @@ __global__ void graph_epilogue_kernel(const float* src, const unsigned long long
 }
 
 int ensure_graph_buffers(rag_bert* h) {
-    if (h->g_pin) return RAG_OK;
-    const size_t pin_ints = (size_t)kGraphCellsAt + 8;
-    RAGC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->g_pin), pin_ints * sizeof(int), hipHostMallocDefault));
-    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_ids), kGraphTokens * sizeof(int)));
-    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_types), kGraphTokens * sizeof(int)));
-    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_cu), (kGraphSeqs + 1) * sizeof(int)));
-    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_cells), 4 * sizeof(unsigned long long)));
+    if (h->g_blk) return RAG_OK;
+    for (int i = 0; i < kGraphStages; ++i) {
+        RAGC_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->g_pin[i]), (size_t)kGraphBlockInts * sizeof(int), hipHostMallocDefault));
+        RAGC_HIP_TRY(hipEventCreateWithFlags(&h->g_up[i], hipEventDisableTiming));
+    }
     RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_out), (size_t)kGraphSeqs * h->cfg.hidden * sizeof(float)));
     RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->g_flag), sizeof(uint32_t)));
-    RAGC_HIP_TRY(hipEventCreateWithFlags(&h->g_done, hipEventDisableTiming));
+    int* blk = nullptr;
+    RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&blk), (size_t)kGraphBlockInts * sizeof(int)));
+    h->g_ids = blk;
+    h->g_types = blk + kGraphTokens;
+    h->g_cu = blk + 2 * kGraphTokens;
+    h->g_cells = reinterpret_cast<unsigned long long*>(blk + kGraphCellsAt);
+    h->g_blk = blk;
+    // A graphed shape must never grow the workspace: its graph — and every other cached one — holds the buffers'
+    // addresses.  Size it once for the largest shape the graph path takes.  (A later eager pass with more tokens still
+    // reallocates; ensure_ws drops the cached graphs when it does.)
+    if (kGraphTokens > h->ws_tokens || kGraphSeqs > h->ws_seqs) {
+        if (h->ws_used) RAGC_HIP_TRY(hipEventSynchronize(h->ws_event));
+        int rc = ensure_ws(h, kGraphTokens, kGraphSeqs);
+        if (rc) return rc;
+    }
     return RAG_OK;
 }
 
-// everything a graphed pass enqueues, in order; called once eagerly (first-use set-up of the kernels) and once under capture
+// everything a graphed pass replays, in order (the block's upload goes in front of it, outside the graph); called once
+// eagerly (first-use set-up of the kernels) and once under capture
 int graph_body(rag_bert* h, int nseq_pad, int T_pad, int maxlen_b, int out_kind, int normalize, hipStream_t st) {
-    int* pin_ids = h->g_pin;
-    int* pin_types = h->g_pin + kGraphTokens;
-    int* pin_cu = h->g_pin + 2 * kGraphTokens;
-    int* pin_cells = h->g_pin + kGraphCellsAt;
-    RAGC_HIP_TRY(hipMemcpyAsync(h->g_ids, pin_ids, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
-    RAGC_HIP_TRY(hipMemcpyAsync(h->g_types, pin_types, (size_t)T_pad * sizeof(int), hipMemcpyHostToDevice, st));
-    RAGC_HIP_TRY(hipMemcpyAsync(h->g_cu, pin_cu, (size_t)(nseq_pad + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-    RAGC_HIP_TRY(hipMemcpyAsync(h->g_cells, pin_cells, 3 * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     RAGC_HIP_TRY(hipMemsetAsync(h->g_flag, 0, sizeof(uint32_t), st));
     int rc = forward_locked(h, h->g_ids, h->cfg.type_vocab > 0 ? h->g_types : nullptr, h->g_cu, nseq_pad, T_pad, maxlen_b, out_kind,
                             normalize, h->g_out, st, h->g_flag);
@@ -761,11 +786,13 @@ int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type
     const int maxlen_b = (std::max(max_len, dummy_len) + 31) / 32 * 32;
     int rc = ensure_graph_buffers(h);
     if (rc) return rc;
-    if (h->g_used) RAGC_HIP_TRY(hipEventSynchronize(h->g_done));   // the previous graphed pass has left the pinned block and the buffers
-    int* pin_ids = h->g_pin;
-    int* pin_types = h->g_pin + kGraphTokens;
-    int* pin_cu = h->g_pin + 2 * kGraphTokens;
-    unsigned long long* pin_cells = reinterpret_cast<unsigned long long*>(h->g_pin + kGraphCellsAt);
+    const unsigned turn = h->g_turn++ % kGraphStages;
+    if (h->g_up_used[turn]) RAGC_HIP_TRY(hipEventSynchronize(h->g_up[turn]));   // this block's previous upload has left it
+    int* pin = h->g_pin[turn];
+    int* pin_ids = pin;
+    int* pin_types = pin + kGraphTokens;
+    int* pin_cu = pin + 2 * kGraphTokens;
+    unsigned long long* pin_cells = reinterpret_cast<unsigned long long*>(pin + kGraphCellsAt);
     std::memcpy(pin_ids, ids, (size_t)T * sizeof(int));
     std::memset(pin_ids + T, 0, (size_t)extra * sizeof(int));
     if (type_ids) std::memcpy(pin_types, type_ids, (size_t)T * sizeof(int));
@@ -781,6 +808,11 @@ int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type
     pin_cells[0] = reinterpret_cast<unsigned long long>(out_dev);
     pin_cells[1] = reinterpret_cast<unsigned long long>(range_flag);
     pin_cells[2] = (unsigned long long)nseq * h->cfg.hidden;
+    // one upload for ids, types, boundaries and cells, behind whatever pass of this handle is still reading the device block
+    if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    RAGC_HIP_TRY(hipMemcpyAsync(h->g_blk, pin, (size_t)kGraphBlockInts * sizeof(int), hipMemcpyHostToDevice, st));
+    RAGC_HIP_TRY(hipEventRecord(h->g_up[turn], st));
+    h->g_up_used[turn] = true;
     hipGraphExec_t exec = nullptr;
     rc = get_graph(h, nseq_pad, T_pad, maxlen_b, out_kind, normalize, st, &exec);
     if (rc) {   // a runtime that cannot capture this (rag_last_error says why): the eager path serves, from now on
@@ -788,14 +820,11 @@ int forward_to_device_graph(rag_bert* h, const int32_t* ids, const int32_t* type
         (void)hipGetLastError();
         return kNotGraphed;
     }
-    if (h->ws_used && h->ws_stream != st) RAGC_HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
     RAGC_HIP_TRY(hipGraphLaunch(exec, st));
     if (hipEventRecord(h->ws_event, st) == hipSuccess) {
         h->ws_stream = st;
         h->ws_used = true;
     }
-    RAGC_HIP_TRY(hipEventRecord(h->g_done, st));
-    h->g_used = true;
     return RAG_OK;
 }
 
@@ -900,11 +929,13 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
         for (_Float16* p : h->wxf)
             if (p) (void)hipFree(p);
         for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
-        void* gptrs[] = {h->g_ids, h->g_types, h->g_cu, h->g_cells, h->g_out, h->g_flag};
+        void* gptrs[] = {h->g_blk, h->g_out, h->g_flag};
         for (void* p : gptrs)
             if (p) (void)hipFree(p);
-        if (h->g_pin) (void)hipHostFree(h->g_pin);
-        if (h->g_done) (void)hipEventDestroy(h->g_done);
+        for (int i = 0; i < kGraphStages; ++i) {
+            if (h->g_pin[i]) (void)hipHostFree(h->g_pin[i]);
+            if (h->g_up[i]) (void)hipEventDestroy(h->g_up[i]);
+        }
         if (h->range_pin) (void)hipHostFree(h->range_pin);
         if (h->stage_pin) (void)hipHostFree(h->stage_pin);
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);

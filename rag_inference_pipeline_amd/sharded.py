@@ -22,6 +22,13 @@ kernel ORs the G words into one, and only when that word is set — on every ran
 rank merges the same gathered buffer — do the ranks repeat the batch through the one-pass fp32 scan
 and gather again.  The caller reads one word back with the results it was going to read anyway.
 
+The collective (C1).  Over RCCL the step is ONE call into the C ABI — rag_index_search_gather_device: local search ->
+ncclAllGather on an own communicator -> flagged merge, all on the caller's stream (include/rag_amd.h, csrc/rag_comm.hip).
+torch.distributed only bootstraps it (the 128-byte unique id travels from rank 0 through the group once) and remains the
+transport of the "gloo" rehearsal path; RAG_AMD_OWN_RCCL=0 keeps torch's collectives on the data path (A/B checks).
+With `overlap_collective` the all-gather and the merge of batch i run on a second stream beside the local search of
+batch i+1, which takes the collective's xGMI latency out of the step when two batches are in flight.
+
 Serving (the product path: FAISSStore.search on rank 0 -> leader_search).  A request is ONE
 fixed-size message `[4 x int64 head | max_batch x d fp32]` that rank 0 fills in pinned memory,
 uploads once and broadcasts once; followers read back only the 32-byte head and hand the query
@@ -30,12 +37,17 @@ uploads once and broadcasts once; followers read back only the 32-byte head and 
 
 from __future__ import annotations
 
+import ctypes as C
+import logging
+import os
 import threading
 from typing import Any, Callable, Protocol
 
 import numpy as np
 
 from ._native import SEARCH_DEFER_FALLBACK, SEARCH_EXACT_ONE_PASS
+
+logger = logging.getLogger(__name__)
 
 OP_SHUTDOWN, OP_SEARCH, OP_RERANK = 0, 1, 2  # first word of the leader's request head
 HEAD_BYTES = 32                               # [op, nq, k, d] as int64
@@ -103,7 +115,7 @@ class ShardedFlatIndex:
 
     def __init__(self, local: _LocalIndex, metric: int = 0, device: int | str | None = None, group: Any = None,
                  merge: Callable[..., None] | None = None, dim: int | None = None, max_batch: int = 32,
-                 depth: int = 2) -> None:
+                 depth: int = 2, overlap_collective: bool | None = None) -> None:
         import torch
         import torch.distributed as dist
 
@@ -136,7 +148,9 @@ class ShardedFlatIndex:
         # holds it around the search.
         self._lock = threading.RLock()
         # the serving message: [4 x int64 head | max_batch x dim fp32], filled by rank 0, ONE broadcast per request
-        self._msg_bytes = HEAD_BYTES + 4 * self.max_batch * self.dim
+        # (every request has this size, whatever its op: a follower posts its receive before it knows what is coming —
+        # 98 KB at d = 768 is 1-2 us of xGMI time, the price of one collective per request instead of two)
+        self._msg_bytes = (HEAD_BYTES + 4 * self.max_batch * self.dim + 7) // 8 * 8
         on_gpu = self.device.type == "cuda"
         self._msg_host = torch.zeros(self._msg_bytes, dtype=torch.uint8)
         self._msg_event = None
@@ -152,6 +166,74 @@ class ShardedFlatIndex:
         # followers over RCCL: the message arrives in device memory and only its head comes back to the host
         self._head_pin = torch.zeros(HEAD_BYTES, dtype=torch.uint8).pin_memory() \
             if on_gpu and self.backend == "nccl" else None
+        # C1: the collectives of the data path on an own RCCL communicator, enqueued by the C ABI on the search's stream
+        self._comm: C.c_void_p | None = None
+        self._comm_stream = None      # second stream for all-gather + merge (overlap_collective)
+        self._req_seq = 0             # requests seen on the serving channel (every rank counts the same ones)
+        self._head_mirror = None      # followers: pinned [head x 4 | seq] the request's last kernel posts
+        if on_gpu and self.backend == "nccl" and merge is None and hasattr(local, "_handle") \
+                and os.environ.get("RAG_AMD_OWN_RCCL", "1") != "0":
+            self._create_comm()
+        if overlap_collective is None:   # from the environment: only where there is a collective to overlap
+            overlap_collective = os.environ.get("RAG_AMD_COMM_OVERLAP", "0") == "1" and self.world > 1
+        if overlap_collective and self._comm is not None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+
+    def _create_comm(self) -> None:
+        """Collective.  Rank 0 draws the unique id, the group's own broadcast carries it (bootstrap only), every rank
+        joins; the ranks then agree (one all-reduce) that all of them hold a communicator — otherwise all fall back to
+        torch's collectives together, so that no rank is left alone inside an RCCL call."""
+        from . import _native
+        torch, dist = self._torch, self._dist
+        lib = _native.lib()
+        ok = 1
+        ident = torch.zeros(128, dtype=torch.uint8)
+        path = _native.rccl_library_path()
+        if lib.rag_comm_runtime(path.encode() if path else None, None) != 0:
+            ok = 0
+            logger.warning("own RCCL communicator unavailable: %s", lib.rag_last_error().decode("utf-8", "replace"))
+        if ok and self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            if lib.rag_comm_unique_id(buf) != 0:
+                ok = 0
+                logger.warning("rag_comm_unique_id failed: %s", lib.rag_last_error().decode("utf-8", "replace"))
+            else:
+                ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        payload = torch.cat([ident, torch.tensor([ok], dtype=torch.uint8)]).to(self.device)
+        dist.broadcast(payload, src=0, group=self.group)
+        payload = payload.cpu()
+        handle = C.c_void_p()
+        if ok and int(payload[128]) == 1:
+            raw = (C.c_uint8 * 128).from_buffer_copy(bytes(payload[:128].tolist()))
+            if lib.rag_comm_create(raw, self.rank, self.world, self.device.index or 0, C.byref(handle)) != 0:
+                ok = 0
+                logger.warning("rag_comm_create failed: %s", lib.rag_last_error().decode("utf-8", "replace"))
+        else:
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)
+        if int(agreed.item()) == 1:
+            self._comm = handle
+            self._head_mirror = torch.zeros(8 * 5, dtype=torch.uint8).pin_memory()
+        else:
+            if handle:
+                lib.rag_comm_destroy(handle)
+            logger.warning("sharded index on rank %d: own RCCL communicator not established on every rank; "
+                           "torch.distributed collectives stay on the data path", self.rank)
+
+    def close(self) -> None:
+        """Release the communicator (every rank, once no search is in flight)."""
+        if self._comm is not None:
+            from . import _native
+            if self.device.type == "cuda":
+                self._torch.cuda.synchronize(self.device)
+            _native.lib().rag_comm_destroy(self._comm)
+            self._comm = None
+
+    @property
+    def own_rccl(self) -> bool:
+        """True when the all-gather and the request broadcast run on this object's own RCCL communicator."""
+        return self._comm is not None
 
     # -- buffers ---------------------------------------------------------------------------------
     def _slot(self, nq: int, k: int) -> _Slot:
@@ -161,11 +243,11 @@ class ShardedFlatIndex:
             ring = self._slots[key] = [_Slot(self, nq, k) for _ in range(self.depth)]
             self._next[key] = 0
         i = self._next[key]
-        self._next[key] = (i + 1) % len(ring)
         slot = ring[i]
-        if slot.pending is not None:
+        if slot.pending is not None:   # (checked BEFORE the cursor moves: a refused submit leaves the ring as it was)
             raise RuntimeError(f"more than {self.depth} searches of shape ({nq}, {k}) in flight: collect() the oldest "
                                "before the next submit()")
+        self._next[key] = (i + 1) % len(ring)
         return slot
 
     def _stream(self) -> int:
@@ -223,9 +305,27 @@ class ShardedFlatIndex:
         nq = int(queries.shape[0])
         s = self._slot(nq, int(k))
         s.pending = queries
-        self._local_search(s, queries, SEARCH_DEFER_FALLBACK)
-        self._gather_and_merge(s)
+        self._step(s, queries, SEARCH_DEFER_FALLBACK)
         return s
+
+    def _step(self, s: _Slot, queries: Any, mode: int) -> None:
+        """local search -> all-gather -> merge for one slot: ONE C-ABI call on the own communicator, else the three
+        pieces with torch's collective in the middle."""
+        if self._comm is None:
+            self._local_search(s, queries, mode)
+            self._gather_and_merge(s)
+            return
+        from . import _native
+        cs = self._comm_stream
+        _native.check(_native.lib().rag_index_search_gather_device(
+            self.local._handle(), self._comm, C.c_void_p(queries.data_ptr()), s.nq, s.k, int(mode),
+            C.c_void_p(s.pack.data_ptr()), C.c_void_p(s.gathered.data_ptr()), C.c_void_p(s.out_s.data_ptr()),
+            C.c_void_p(s.out_i.data_ptr()), C.c_void_p(s.out_any.data_ptr()), C.c_void_p(s.res_host.data_ptr()),
+            C.c_void_p(self._stream()), C.c_void_p(cs.cuda_stream) if cs is not None else None))
+        if cs is not None:
+            s.event.record(cs)
+        else:
+            s.event.record()
 
     def collect(self, s: _Slot) -> tuple[Any, Any]:
         """Collective: wait for submit()'s search; if some rank's two-stage certificate failed (the same word
@@ -237,8 +337,7 @@ class ShardedFlatIndex:
         if s.event is not None:
             s.event.synchronize()
         if int(s.host_any[0]) != 0:
-            self._local_search(s, s.pending, SEARCH_EXACT_ONE_PASS)
-            self._gather_and_merge(s)
+            self._step(s, s.pending, SEARCH_EXACT_ONE_PASS)
             if s.event is not None:
                 s.event.synchronize()
             s.repeats += 1
@@ -271,6 +370,19 @@ class ShardedFlatIndex:
     def _broadcast_msg(self) -> None:
         """Rank 0 has filled the pinned message; afterwards every rank holds it in `_msg_dev`."""
         dist = self._dist
+        if self._comm is not None:
+            # upload (rank 0) + ncclBroadcast + a last kernel that posts head and sequence number to pinned host
+            # memory on the followers — all on the search's stream, one C-ABI call
+            from . import _native
+            self._req_seq += 1
+            leader = self.rank == 0
+            _native.check(_native.lib().rag_comm_request_device(
+                self._comm, C.c_void_p(self._msg_host.data_ptr()) if leader else None,
+                C.c_void_p(self._msg_dev.data_ptr()), self._msg_bytes, 0,
+                None if leader else C.c_void_p(self._head_mirror.data_ptr()), self._req_seq, C.c_void_p(self._stream())))
+            if leader:
+                self._msg_event.record()
+            return
         if self.backend == "nccl":
             if self.rank == 0:
                 self._msg_dev.copy_(self._msg_host, non_blocking=True)  # the batch is uploaded once
@@ -346,9 +458,15 @@ class ShardedFlatIndex:
         torch = self._torch
         served = 0
         head_np = self._head_pin.numpy().view(np.int64) if self._head_pin is not None else self._msg_head_np
+        head_c = (C.c_int64 * 4)()
         while True:
             self._broadcast_msg()
-            if self._head_pin is not None:  # only the 32-byte head comes back to the host
+            if self._comm is not None:   # the request's last kernel posts the head: poll one host word, no stream sync
+                from . import _native
+                _native.check(_native.lib().rag_comm_wait_head(C.c_void_p(self._head_mirror.data_ptr()), self._req_seq,
+                                                               -1, head_c))
+                head_np = np.frombuffer(head_c, dtype=np.int64)
+            elif self._head_pin is not None:  # only the 32-byte head comes back to the host
                 self._head_pin.copy_(self._msg_dev[:HEAD_BYTES], non_blocking=True)
                 torch.cuda.current_stream(self.device).synchronize()
             op, nq, k, d = (int(v) for v in head_np)

@@ -13,7 +13,12 @@ size 1 (every collective call the N-GPU run makes is made; what is missing is th
   leader_search     the step the PRODUCT serves (FAISSStore.search on rank 0): host queries -> pinned message ->
                     one upload -> one broadcast -> search_tensors -> ids and scores on the host
 
-Prints one JSON object (committed as profiles/r03_shard_step.json)."""
+Round 4: the ShardedFlatIndex step runs on the library's OWN RCCL communicator (rag_index_search_gather_device: local
+search -> ncclAllGather -> merge in one C-ABI call on one stream; rag_comm_request_device for the request).  The
+same legs through torch.distributed's collectives (RAG_AMD_OWN_RCCL=0) are reported beside them as `torch_collectives`,
+and the pipelined leg once more with the all-gather + merge on a second stream (`pipelined_overlap_ms`).
+
+Prints one JSON object (committed as profiles/r04_shard_step.json)."""
 import json
 import os
 import sys
@@ -33,6 +38,12 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 d, B, k = 768, 32, 10
 idx = FlatIndex(d); idx.add_synthetic(rows, 1234)
 sh = ShardedFlatIndex(idx, 0, device=0)
+assert sh.own_rccl, "the own RCCL communicator was not established"
+sh_over = ShardedFlatIndex(idx, 0, device=0, overlap_collective=True)
+os.environ["RAG_AMD_OWN_RCCL"] = "0"
+sh_torch = ShardedFlatIndex(idx, 0, device=0)
+del os.environ["RAG_AMD_OWN_RCCL"]
+assert not sh_torch.own_rccl
 Qh = oracle.synth_rows(4321, 0, B, d)
 Q = torch.from_numpy(Qh).cuda()
 out_s = torch.empty((B, k), dtype=torch.float32, device="cuda")
@@ -72,18 +83,20 @@ timed.warm = False
 pend = []
 
 
-def pipelined():
-    pend.append(sh.submit(Q, k))
-    if len(pend) > 1:
-        sh.collect(pend.pop(0))
+def make_pipelined(link):
+    def step():
+        pend.append(link.submit(Q, k))
+        if len(pend) > 1:
+            link.collect(pend.pop(0))
+
+    def drain():
+        while pend:
+            link.collect(pend.pop(0))
+    return step, drain
 
 
-def drain():
-    while pend:
-        sh.collect(pend.pop(0))
-
-
-res = {"rows": rows, "dim": d, "batch": B, "k": k, "steps": steps, "world": 1, "backend": sh.backend}
+res = {"rows": rows, "dim": d, "batch": B, "k": k, "steps": steps, "world": 1, "backend": sh.backend,
+       "collective": "own RCCL communicator inside the C ABI (rag_index_search_gather_device)"}
 ref = None
 for mode in ("one_pass", "two_stage"):
     if mode == "two_stage":
@@ -94,7 +107,12 @@ for mode in ("one_pass", "two_stage"):
     deferred_ms, _ = timed(lambda: idx.search_device_ex(Q.data_ptr(), B, k, out_s.data_ptr(), out_i.data_ptr(),
                                                         SEARCH_DEFER_FALLBACK, flag.data_ptr(), sptr))
     sync_ms, _ = timed(lambda: sh.search_tensors(Q, k))
-    pipe_ms, _ = timed(pipelined, drain)
+    pipe_ms, _ = timed(*make_pipelined(sh))
+    over_ms, _ = timed(*make_pipelined(sh_over))
+    t_sync_ms, _ = timed(lambda: sh_torch.search_tensors(Q, k))
+    t_pipe_ms, _ = timed(*make_pipelined(sh_torch))
+    t_lead_ms, _ = timed(lambda: sh_torch.leader_search(Qh, k))
+    t_lead_p50, _ = percentiles(lambda: sh_torch.leader_search(Qh, k))
     s2, i2 = sh.search_tensors(Q, k); torch.cuda.synchronize()
     same = bool(np.array_equal(i2.cpu().numpy(), ids) and np.array_equal(s2.cpu().numpy().view(np.uint32), sc.view(np.uint32)))
     lead_ms, _ = timed(lambda: sh.leader_search(Qh, k))
@@ -107,6 +125,9 @@ for mode in ("one_pass", "two_stage"):
     res[mode] = {"search_device_ms": round(local_ms, 4), "search_deferred_ms": round(deferred_ms, 4),
                  "scan_kernel_ms": round(scan_ms, 4),
                  "search_tensors_ms": round(sync_ms, 4), "pipelined_submit_collect_ms": round(pipe_ms, 4),
+                 "pipelined_overlap_ms": round(over_ms, 4),
+                 "torch_collectives": {"search_tensors_ms": round(t_sync_ms, 4), "pipelined_submit_collect_ms": round(t_pipe_ms, 4),
+                                       "leader_search_ms": round(t_lead_ms, 4), "leader_search_p50_ms": round(t_lead_p50, 4)},
                  "leader_search_ms": round(lead_ms, 4), "leader_search_p50_ms": round(lead_p50, 4),
                  "leader_search_p95_ms": round(lead_p95, 4), "rag_index_search_host_ms": round(host_ms, 4),
                  "scan_GBps": round((4.0 if mode == "one_pass" else 2.0) * rows * d / (scan_ms * 1e-3) / 1e9, 1),
@@ -116,4 +137,6 @@ if idx.screening == SCREEN_FP16:
     res["two_stage"]["fallbacks"] = idx.screen_stats()["fallbacks"]
     res["two_stage"]["repeats_through_fp32"] = sh.repeats
 print(json.dumps(res), flush=True)
+for link in (sh, sh_over, sh_torch):
+    link.close()
 dist.destroy_process_group()

@@ -94,13 +94,37 @@ def main() -> None:
     D2, I2 = sharded.search(Q[: max(1, nq // 2)], k)  # a second shape re-uses the group
     if mode == "cpuflag":
         extra["repeats_total"] = sharded.repeats
+    if mode == "nccl":
+        # C1: the step runs on the library's own RCCL communicator unless the environment turns that off
+        want_own = os.environ.get("RAG_AMD_OWN_RCCL", "1") != "0"
+        assert sharded.own_rccl == want_own, (sharded.own_rccl, want_own)
+        # two-stage local searches, two batches in flight, then the same with all-gather + merge on a second stream
+        local.set_screening(True)
+        Qr = np.ascontiguousarray(Q[::-1])
+        qa, qb = torch.from_numpy(Q).to(sharded.device), torch.from_numpy(Qr).to(sharded.device)
+        ta, tb = sharded.submit(qa, k), sharded.submit(qb, k)
+        sharded.collect(ta)
+        D4, I4 = ta.host_s.numpy().copy(), ta.host_i.numpy().copy()
+        sharded.collect(tb)
+        D5, I5 = tb.host_s.numpy().copy(), tb.host_i.numpy().copy()
+        over = ShardedFlatIndex(local, metric, device=dev, overlap_collective=True)
+        assert (over._comm_stream is not None) == want_own
+        ta, tb = over.submit(qa, k), over.submit(qb, k)
+        over.collect(ta)
+        D6, I6 = ta.host_s.numpy().copy(), ta.host_i.numpy().copy()
+        over.collect(tb)
+        D7, I7 = tb.host_s.numpy().copy(), tb.host_i.numpy().copy()
+        over.close()
+        extra = dict(D4=D4, I4=I4, D5=D5, I5=I5, D6=D6, I6=I6, D7=D7, I7=I7, own=int(sharded.own_rccl))
     if mode == "nccl":  # the serving protocol over RCCL: control words and the batch travel on the device
         if rank == 0:
             D3, I3 = sharded.leader_search(Q, k)
+            D8, I8 = sharded.leader_search(Q[:3], k)   # a second request: the sequence number moves on
             sharded.shutdown()
-            extra = dict(D3=D3, I3=I3)
+            extra.update(D3=D3, I3=I3, D8=D8, I8=I8)
         else:
-            extra = dict(served=sharded.follower_loop())
+            extra.update(served=sharded.follower_loop())
+        sharded.close()
     np.savez(out_path, D=D, I=I, D2=D2, I2=I2, lo=lo, hi=hi, **extra)
     dist.barrier()
     dist.destroy_process_group()

@@ -372,6 +372,41 @@ def test_query_encoder_replays_a_graph_per_padded_shape(gpu_required, monkeypatc
     eager.close()
 
 
+def test_cached_encoder_graphs_survive_a_workspace_reallocation(gpu_required, monkeypatch):
+    """A cached graph holds the activation workspace's addresses.  A later pass that needs a bigger workspace — an eager
+    embed() of more tokens than the graph path ever takes — frees and reallocates those buffers; the next replay of the
+    small shape must not run into the freed ones (round 3's graphs did: advisor finding).  Sequence: capture a small
+    shape, grow the workspace well past the graph path's 1024 tokens, replay the small shape several times with other
+    models allocating in between, compare with the eager model; then three batches back to back without reading any
+    (two staging blocks take turns, the third call waits for the first's upload only)."""
+    cfg = _small(BertConfig.minilm_l6())
+    cfg.n_layers = 2
+    w = random_weights(cfg, 77)
+    graphed = BertModel(cfg, w)
+    monkeypatch.setenv("RAG_AMD_ENCODER_GRAPH", "0")
+    eager = BertModel(cfg, w)
+    monkeypatch.delenv("RAG_AMD_ENCODER_GRAPH")
+    rng = np.random.default_rng(77)
+    small = _seqs(rng, rng.integers(4, 12, size=3), cfg.vocab_size)
+    ref_small = eager.embed(small)
+    np.testing.assert_allclose(graphed.embed_to_device(small).numpy(), ref_small, atol=3e-6, rtol=1e-5)   # captured
+    big = _seqs(rng, rng.integers(60, 100, size=40), cfg.vocab_size)          # ~3200 tokens: the workspace grows
+    np.testing.assert_allclose(graphed.embed(big), eager.embed(big), atol=2e-5, rtol=1e-4)
+    other = BertModel(cfg, random_weights(cfg, 78))                            # something else takes the freed ranges
+    other.embed(big)
+    for _ in range(3):
+        np.testing.assert_allclose(graphed.embed_to_device(small).numpy(), ref_small, atol=3e-6, rtol=1e-5)
+    bigger = _seqs(rng, rng.integers(60, 100, size=90), cfg.vocab_size)       # ~7200 tokens: grows again
+    graphed.embed(bigger)
+    np.testing.assert_allclose(graphed.embed_to_device(small).numpy(), ref_small, atol=3e-6, rtol=1e-5)
+    batches = [_seqs(rng, rng.integers(8, 21, size=32), cfg.vocab_size) for _ in range(3)]
+    handles = [graphed.embed_to_device(b) for b in batches]
+    for h, b in zip(reversed(handles), reversed(batches)):
+        np.testing.assert_allclose(h.numpy(), eager.embed(b), atol=3e-6, rtol=1e-5)
+    for m in (graphed, eager, other):
+        m.close()
+
+
 @pytest.mark.parametrize("hidden,heads,inter,head,seed", [
     (256, 8, 672, "none", 41),        # DH 32, N = 672 = 5.25 tiles of 128, K = 256
     (512, 8, 1568, "bert", 42),       # DH 64, intermediate 1568 (not a multiple of 64): K >= 1536 on the way back

@@ -32,8 +32,128 @@ def test_header_symbols_are_all_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.rag_abi_version() == 1
+    assert lib.rag_abi_version() == _native.header_abi_version() >= 4
     assert isinstance(lib.rag_last_error(), bytes)
+
+
+# ---- the ctypes table against the header's prototypes ---------------------------------------------------
+
+def _kind_of_c(decl: str) -> str:
+    """'ptr' | 'i32' | 'u32' | 'i64' | 'u64' | 'int' | 'f32' | 'f64' | 'void' for one C parameter or return type."""
+    d = re.sub(r"\bconst\b", " ", decl).strip()
+    if "*" in d:
+        return "ptr"
+    base = d.split()[0] if d.split() else ""
+    return {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "int": "int", "float": "f32",
+            "double": "f64", "void": "void"}[base]
+
+
+def _kind_of_ctypes(t) -> str:
+    if t is None:
+        return "void"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or issubclass(t, ctypes._Pointer):
+        return "ptr"
+    return {ctypes.c_int32: "i32", ctypes.c_uint32: "u32", ctypes.c_int64: "i64", ctypes.c_uint64: "u64",
+            ctypes.c_int: "int", ctypes.c_float: "f32", ctypes.c_double: "f64"}[t]
+
+
+def _header_prototypes():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", "", text, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(rag_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        args = [] if params in ("", "void") else [_kind_of_c(a) for a in params.split(",")]
+        protos[name] = (_kind_of_c(ret), args)
+    return protos
+
+
+def test_ctypes_table_matches_every_prototype_of_the_header():
+    """Argument COUNT and pointer / integer-width KIND of every entry point, header against _native.signatures().
+    (c_int and int32_t are both 'a 32-bit int' on this ABI; the test keeps them apart anyway: the header is the
+    contract.)  A prototype that gains an argument without the table following — or the other way round — fails here,
+    on the CPU, instead of passing a stream handle where a flag pointer is expected."""
+    protos = _header_prototypes()
+    table = _native.signatures()
+    assert set(protos) == set(table), (sorted(set(protos) - set(table)), sorted(set(table) - set(protos)))
+    same_width = {"int": "i32"}
+    for name, (ret, args) in protos.items():
+        res, argtypes = table[name]
+        got_ret, got_args = _kind_of_ctypes(res), [_kind_of_ctypes(t) for t in argtypes]
+        norm = lambda k: same_width.get(k, k)  # noqa: E731
+        assert norm(got_ret) == norm(ret), f"{name}: return {got_ret} in the table, {ret} in the header"
+        assert len(got_args) == len(args), f"{name}: {len(got_args)} arguments in the table, {len(args)} in the header"
+        for i, (g, w) in enumerate(zip(got_args, args)):
+            assert norm(g) == norm(w), f"{name}: argument {i} is {g} in the table, {w} in the header"
+
+
+def test_bert_config_struct_matches_the_header():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct rag_bert_config \{(.*?)\} rag_bert_config;", text, flags=re.S).group(1)
+    fields = [(t, n) for t, n in re.findall(r"\b(int32_t|float|uint32_t|int64_t)\s+([a-z_0-9]+)\s*;", body)]
+    want = [(n, {"int32_t": ctypes.c_int32, "float": ctypes.c_float}[t]) for t, n in fields]
+    assert want == list(_native.BertConfigStruct._fields_)
+
+
+def test_stale_library_is_detected_by_content_not_by_mtime(lib, tmp_path, monkeypatch):
+    """The library carries the digest of the sources it was built from; the loader compares it with the sources beside
+    it.  A copy of the tree with one source byte changed is stale whatever the timestamps say, and with no compiler
+    at hand the loader refuses it instead of calling it through a newer argument table."""
+    import shutil
+    assert _native.built_digest() == _native.source_digest()
+    assert lib.rag_source_digest().decode() == "rag-amd-source-digest:" + _native.source_digest()
+    csrc = tmp_path / "csrc"
+    shutil.copytree(_native._CSRC, csrc, ignore=shutil.ignore_patterns("build", "*.lock", "*.tmp.*"))
+    monkeypatch.setattr(_native, "_CSRC", str(csrc))
+    monkeypatch.setattr(_native, "LIB_PATH", str(csrc / "librag_amd.so"))
+    assert not _native.needs_build()
+    with open(csrc / "rag_common.h", "a") as f:
+        f.write("// edited\n")
+    os.utime(csrc / "rag_common.h", (0, 0))          # older than the library: mtime would say "fresh"
+    assert _native.needs_build()
+    monkeypatch.setenv("RAG_AMD_NO_REBUILD", "1")
+    with pytest.raises(_native.NativeLibraryError, match="stale"):
+        _native._ensure_current()
+    monkeypatch.delenv("RAG_AMD_NO_REBUILD")
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setattr(_native.shutil, "which", lambda name: None)
+    monkeypatch.setattr(_native.os.path, "exists", lambda p, _e=os.path.exists: False if p == "/opt/rocm/bin/hipcc" else _e(p))
+    with pytest.raises(_native.NativeLibraryError, match="could not be rebuilt"):
+        _native._ensure_current()
+
+
+def test_pack_layout_is_one_definition(lib):
+    from rag_inference_pipeline_amd.sharded import pack_layout
+    for nq, k in ((32, 10), (1, 1), (7, 100), (32, 100), (3, 5)):
+        s, f, b = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        assert lib.rag_pack_layout(nq, k, ctypes.byref(s), ctypes.byref(f), ctypes.byref(b)) == 0
+        assert (s.value, f.value, b.value) == pack_layout(nq, k)
+    assert lib.rag_pack_layout(0, 10, None, None, None) == _native.RAG_ERR_INVALID_ARG
+
+
+def test_rccl_binds_at_run_time_and_argument_errors_are_status_codes(lib):
+    """C1's entry points without a GPU: RCCL is found and bound (the copy torch has mapped, else ROCm's), every bad
+    argument is a status code.  No communicator is created here (that needs a device)."""
+    ver = ctypes.c_int32(0)
+    rc = lib.rag_comm_runtime(None, ctypes.byref(ver))
+    if rc != 0:
+        pytest.skip("no librccl on this machine: " + lib.rag_last_error().decode())
+    assert ver.value >= 20000
+    assert lib.rag_comm_create(None, 0, 1, 0, ctypes.byref(ctypes.c_void_p())) == _native.RAG_ERR_INVALID_ARG
+    ident = (ctypes.c_uint8 * 128)()
+    assert lib.rag_comm_create(ident, 2, 2, 0, ctypes.byref(ctypes.c_void_p())) == _native.RAG_ERR_INVALID_ARG
+    assert lib.rag_comm_destroy(None) == 0 and lib.rag_comm_world(None) == 0 and lib.rag_comm_rank(None) == -1
+    assert lib.rag_comm_all_gather_device(None, None, None, 8, None) == _native.RAG_ERR_INVALID_ARG
+    assert lib.rag_comm_request_device(None, None, None, 64, 0, None, 1, None) == _native.RAG_ERR_INVALID_ARG
+    # the head mirror protocol is plain host memory: a posted head is seen, a missing one times out
+    mirror = (ctypes.c_uint64 * 5)(1, 32, 10, 768, 0)
+    head = (ctypes.c_int64 * 4)()
+    assert lib.rag_comm_wait_head(mirror, 7, 2000, head) == _native.RAG_ERR_STATE
+    mirror[4] = 7
+    assert lib.rag_comm_wait_head(mirror, 7, 2000, head) == 0 and list(head) == [1, 32, 10, 768]
 
 
 def test_invalid_arguments_are_status_codes_not_crashes(lib):

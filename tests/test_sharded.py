@@ -19,7 +19,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _launch(mode, world, tmp_path, n, d, nq, k, metric):
+def _launch(mode, world, tmp_path, n, d, nq, k, metric, env=None):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
@@ -28,7 +28,7 @@ def _launch(mode, world, tmp_path, n, d, nq, k, metric):
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(HERE, "_sharded_worker.py"), mode, str(r), str(world), str(port), out,
              str(n), str(d), str(nq), str(k), str(metric)],
-            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", **(env or {}))))
     try:
         for p in procs:
             assert p.wait(timeout=300) == 0
@@ -165,17 +165,32 @@ def _nccl_worlds():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", _nccl_worlds())
-@pytest.mark.parametrize("metric,k", [(0, 10), (1, 100)])
-def test_sharded_search_over_rccl(gpu_required, tmp_path, world, metric, k):
-    """BASELINE config D's collective leg: backend "nccl" — `all_gather_into_tensor` of the packed
-    per-shard results over RCCL, merged in place on the device, and the leader/follower protocol with its
-    control words on the device.  Ids and score bits equal the oracle's on every rank."""
+@pytest.mark.parametrize("metric,k,own", [(0, 10, "1"), (1, 100, "1"), (0, 10, "0")])
+def test_sharded_search_over_rccl(gpu_required, tmp_path, world, metric, k, own):
+    """BASELINE config D's collective leg: backend "nccl".  own = "1" (the product): the whole step — local search,
+    ncclAllGather on the library's own communicator, flagged merge — is ONE C-ABI call on one stream
+    (rag_index_search_gather_device), the request broadcast another (rag_comm_request_device) with the followers
+    polling the posted head; own = "0": torch.distributed's collectives in the same places.  Either way ids and score
+    bits equal the oracle's on every rank — one-pass and two-stage, two batches in flight, with the collective on
+    its own stream, and through the leader/follower protocol."""
     n, d, nq = 60_007, 768, 32
-    results = _launch("nccl", world, tmp_path, n, d, nq, k, metric)
+    results = _launch("nccl", world, tmp_path, n, d, nq, k, metric, env={"RAG_AMD_OWN_RCCL": own})
     _check(results, n, d, nq, k, metric, world)
-    np.testing.assert_array_equal(results[0]["I3"], results[0]["I"])
-    np.testing.assert_array_equal(results[0]["D3"], results[0]["D"])
-    assert all(int(r["served"]) == 1 for r in results[1:])
+    lead = results[0]
+    assert int(lead["own"]) == int(own)
+    np.testing.assert_array_equal(lead["I3"], lead["I"])
+    np.testing.assert_array_equal(lead["D3"], lead["D"])
+    np.testing.assert_array_equal(lead["I8"], lead["I"][:3])
+    np.testing.assert_array_equal(lead["D8"], lead["D"][:3])
+    Qr = np.ascontiguousarray(oracle.synth_rows(4321, 0, nq, d)[::-1])
+    Dr, Ir = oracle.search(oracle.synth_rows(1234, 0, n, d), Qr, k, metric)
+    for res in results:   # two-stage, two in flight; then the same with all-gather + merge on a second stream
+        for a, b in (("4", "5"), ("6", "7")):
+            np.testing.assert_array_equal(res["I" + a], lead["I"])
+            np.testing.assert_array_equal(res["D" + a], lead["D"])
+            np.testing.assert_array_equal(res["I" + b], Ir)
+            np.testing.assert_array_equal(res["D" + b], Dr)
+    assert all(int(r["served"]) == 2 for r in results[1:])
 
 
 @pytest.mark.gpu
