@@ -29,10 +29,14 @@ transport of the "gloo" rehearsal path; RAG_AMD_OWN_RCCL=0 keeps torch's collect
 With `overlap_collective` the all-gather and the merge of batch i run on a second stream beside the local search of
 batch i+1, which takes the collective's xGMI latency out of the step when two batches are in flight.
 
-Serving (the product path: FAISSStore.search on rank 0 -> leader_search).  A request is ONE
-fixed-size message `[4 x int64 head | max_batch x d fp32]` that rank 0 fills in pinned memory,
-uploads once and broadcasts once; followers read back only the 32-byte head and hand the query
-*device pointer* inside the message buffer straight to the local search.
+Serving (the product path: FAISSStore.search on rank 0 -> leader_search).  A request is ONE fixed-size message
+`[4 x int64 head | max_batch x d fp32]` that rank 0 fills in pinned memory, uploads once and broadcasts once; followers
+learn its head from a posted store (own communicator) or a 32-byte read-back and hand the query *device pointer* inside
+the message buffer straight to the local search.  Round 4: the leader decides everything — a batch whose flag came
+back set is re-sent as an OP_SEARCH_EXACT request — so followers never wait for a result: they take the next request
+while the previous batch is still on the GPU, and rank 0 keeps up to `depth` requests in flight from as many threads
+(the reference's scheduler runs batches concurrently, batch_scheduler.py:286-288).  With `overlap_collective` requests
+travel on a communicator and stream of their own, so neither the broadcast nor the all-gather sits between two scans.
 """
 
 from __future__ import annotations
@@ -49,7 +53,7 @@ from ._native import SEARCH_DEFER_FALLBACK, SEARCH_EXACT_ONE_PASS
 
 logger = logging.getLogger(__name__)
 
-OP_SHUTDOWN, OP_SEARCH, OP_RERANK = 0, 1, 2  # first word of the leader's request head
+OP_SHUTDOWN, OP_SEARCH, OP_RERANK, OP_SEARCH_EXACT = 0, 1, 2, 3  # first word of the leader's request head
 HEAD_BYTES = 32                               # [op, nq, k, d] as int64
 
 
@@ -99,8 +103,29 @@ class _Slot:
             self.pack_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if on_gpu \
                 else torch.empty(nbytes, dtype=torch.uint8)
             self.gathered_host = torch.empty(world * nbytes, dtype=torch.uint8)
+        # the slot's buffers as the C ABI takes them, wrapped once (rag_index_search_gather_device is called per batch)
+        self.c_args = tuple(C.c_void_p(t.data_ptr()) for t in (self.pack, self.gathered, self.out_s, self.out_i,
+                                                               self.out_any, self.res_host))
         self.pending: Any = None   # the query tensor of the search in flight (kept alive for a repeat)
         self.repeats = 0           # fp32 repeats this slot has run (tests, stats)
+
+
+class _Message:
+    """One serving message: pinned host block (rank 0 fills it), device block (every rank receives into it)."""
+
+    def __init__(self, owner: "ShardedFlatIndex", on_gpu: bool) -> None:
+        torch = owner._torch
+        self.host = torch.zeros(owner._msg_bytes, dtype=torch.uint8)
+        self.event = None
+        if on_gpu:
+            self.host = self.host.pin_memory()
+            self.dev = torch.zeros(owner._msg_bytes, dtype=torch.uint8, device=owner.device)
+            self.event = torch.cuda.Event()
+        else:
+            self.dev = self.host
+        self.head_np = self.host[:HEAD_BYTES].numpy().view(np.int64)
+        self.q_np = self.host[HEAD_BYTES:].numpy().view(np.float32)
+        self.q_dev = self.dev[HEAD_BYTES:].view(torch.float32)
 
 
 class ShardedFlatIndex:
@@ -147,39 +172,40 @@ class ShardedFlatIndex:
         # the followers replay in order, so two of them must never interleave.  Re-entrant: leader_search
         # holds it around the search.
         self._lock = threading.RLock()
-        # the serving message: [4 x int64 head | max_batch x dim fp32], filled by rank 0, ONE broadcast per request
+        # the serving messages: [4 x int64 head | max_batch x dim fp32], filled by rank 0, ONE broadcast per request;
+        # request number s uses message s % depth on every rank (at most `depth` requests are in flight and they finish
+        # in stream order, so by the time a message is reused the search that read it is done)
         # (every request has this size, whatever its op: a follower posts its receive before it knows what is coming —
         # 98 KB at d = 768 is 1-2 us of xGMI time, the price of one collective per request instead of two)
         self._msg_bytes = (HEAD_BYTES + 4 * self.max_batch * self.dim + 7) // 8 * 8
         on_gpu = self.device.type == "cuda"
-        self._msg_host = torch.zeros(self._msg_bytes, dtype=torch.uint8)
-        self._msg_event = None
-        if on_gpu:
-            self._msg_host = self._msg_host.pin_memory()
-            self._msg_dev = torch.zeros(self._msg_bytes, dtype=torch.uint8, device=self.device)
-            self._msg_event = torch.cuda.Event()
-        else:
-            self._msg_dev = self._msg_host
-        self._msg_head_np = self._msg_host[:HEAD_BYTES].numpy().view(np.int64)
-        self._msg_q_np = self._msg_host[HEAD_BYTES:].numpy().view(np.float32)
-        self._msg_q_dev = self._msg_dev[HEAD_BYTES:].view(torch.float32)
+        self._msgs = [_Message(self, on_gpu) for _ in range(self.depth)]
+        self._req_seq = 0             # requests seen on the serving channel (every rank counts the same ones)
+        self._inflight = 0            # rank 0: search requests enqueued and not yet finished
+        self._cv = threading.Condition(self._lock)
         # followers over RCCL: the message arrives in device memory and only its head comes back to the host
         self._head_pin = torch.zeros(HEAD_BYTES, dtype=torch.uint8).pin_memory() \
             if on_gpu and self.backend == "nccl" else None
         # C1: the collectives of the data path on an own RCCL communicator, enqueued by the C ABI on the search's stream
         self._comm: C.c_void_p | None = None
         self._comm_stream = None      # second stream for all-gather + merge (overlap_collective)
-        self._req_seq = 0             # requests seen on the serving channel (every rank counts the same ones)
+        self._req_comm: C.c_void_p | None = None   # overlap_collective: requests on a communicator and stream of their own
+        self._req_stream = None
         self._head_mirror = None      # followers: pinned [head x 4 | seq] the request's last kernel posts
         if on_gpu and self.backend == "nccl" and merge is None and hasattr(local, "_handle") \
                 and os.environ.get("RAG_AMD_OWN_RCCL", "1") != "0":
-            self._create_comm()
+            self._comm = self._create_comm()
+            if self._comm is not None:
+                self._head_mirror = torch.zeros(8 * 5, dtype=torch.uint8).pin_memory()
         if overlap_collective is None:   # from the environment: only where there is a collective to overlap
             overlap_collective = os.environ.get("RAG_AMD_COMM_OVERLAP", "0") == "1" and self.world > 1
         if overlap_collective and self._comm is not None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
+            self._req_comm = self._create_comm()
+            if self._req_comm is not None:
+                self._req_stream = torch.cuda.Stream(device=self.device)
 
-    def _create_comm(self) -> None:
+    def _create_comm(self) -> "C.c_void_p | None":
         """Collective.  Rank 0 draws the unique id, the group's own broadcast carries it (bootstrap only), every rank
         joins; the ranks then agree (one all-reduce) that all of them hold a communicator — otherwise all fall back to
         torch's collectives together, so that no rank is left alone inside an RCCL call."""
@@ -213,22 +239,23 @@ class ShardedFlatIndex:
         agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)
         if int(agreed.item()) == 1:
-            self._comm = handle
-            self._head_mirror = torch.zeros(8 * 5, dtype=torch.uint8).pin_memory()
-        else:
-            if handle:
-                lib.rag_comm_destroy(handle)
-            logger.warning("sharded index on rank %d: own RCCL communicator not established on every rank; "
-                           "torch.distributed collectives stay on the data path", self.rank)
+            return handle
+        if handle:
+            lib.rag_comm_destroy(handle)
+        logger.warning("sharded index on rank %d: own RCCL communicator not established on every rank; "
+                       "torch.distributed collectives stay on the data path", self.rank)
+        return None
 
     def close(self) -> None:
         """Release the communicator (every rank, once no search is in flight)."""
-        if self._comm is not None:
+        if self._comm is not None or self._req_comm is not None:
             from . import _native
             if self.device.type == "cuda":
                 self._torch.cuda.synchronize(self.device)
-            _native.lib().rag_comm_destroy(self._comm)
-            self._comm = None
+            for comm in (self._req_comm, self._comm):
+                if comm is not None:
+                    _native.lib().rag_comm_destroy(comm)
+            self._comm = self._req_comm = None
 
     @property
     def own_rccl(self) -> bool:
@@ -318,9 +345,7 @@ class ShardedFlatIndex:
         from . import _native
         cs = self._comm_stream
         _native.check(_native.lib().rag_index_search_gather_device(
-            self.local._handle(), self._comm, C.c_void_p(queries.data_ptr()), s.nq, s.k, int(mode),
-            C.c_void_p(s.pack.data_ptr()), C.c_void_p(s.gathered.data_ptr()), C.c_void_p(s.out_s.data_ptr()),
-            C.c_void_p(s.out_i.data_ptr()), C.c_void_p(s.out_any.data_ptr()), C.c_void_p(s.res_host.data_ptr()),
+            self.local._handle(), self._comm, C.c_void_p(queries.data_ptr()), s.nq, s.k, int(mode), *s.c_args,
             C.c_void_p(self._stream()), C.c_void_p(cs.cuda_stream) if cs is not None else None))
         if cs is not None:
             s.event.record(cs)
@@ -364,62 +389,77 @@ class ShardedFlatIndex:
     # -- serving: rank 0 answers requests, the other ranks follow -------------------------------------
     # The reference's retrieval node is ONE process (uvicorn) calling index.search(); with the corpus
     # split over G ranks, rank 0 keeps that role.  Every request it serves is one fixed-size message
-    # [op, nq, k, d | queries] broadcast to the followers, which sit in follower_loop(): OP_SEARCH runs
-    # the collective search on the queries inside the message; other ops run a handler a component
-    # registered (the reranker's query-sharded pass, components/reranker.py); OP_SHUTDOWN ends the loop.
-    def _broadcast_msg(self) -> None:
-        """Rank 0 has filled the pinned message; afterwards every rank holds it in `_msg_dev`."""
+    # [op, nq, k, d | queries] broadcast to the followers, which sit in follower_loop(): OP_SEARCH /
+    # OP_SEARCH_EXACT enqueue the collective search on the queries inside the message (two-stage with a
+    # deferred fallback / one-pass fp32); other ops run a handler a component registered (the reranker's
+    # query-sharded pass, components/reranker.py); OP_SHUTDOWN ends the loop.
+    def _request(self, op: int, nq: int = 0, k: int = 0, d: int = 0, queries: np.ndarray | None = None) -> _Message:
+        """One request on the channel (the caller holds the lock).  Rank 0 passes the head (and the batch); the other
+        ranks pass nothing and receive.  Afterwards every rank holds the message in `msg.dev`; on followers the head
+        is in `self._last_head`.  The search that follows is ordered behind the message on the device."""
         dist = self._dist
+        self._req_seq += 1
+        msg = self._msgs[self._req_seq % len(self._msgs)]
+        leader = self.rank == 0
+        if leader:
+            if msg.event is not None and self.backend == "nccl":
+                msg.event.synchronize()   # (long done: see the ring's rule above; this is the cheap proof)
+            msg.head_np[:] = (op, nq, k, d)
+            if queries is not None:
+                msg.q_np[:nq * self.dim].reshape(nq, self.dim)[...] = queries
         if self._comm is not None:
             # upload (rank 0) + ncclBroadcast + a last kernel that posts head and sequence number to pinned host
-            # memory on the followers — all on the search's stream, one C-ABI call
+            # memory on the followers: one C-ABI call; on a communicator and stream of its own when there is one
             from . import _native
-            self._req_seq += 1
-            leader = self.rank == 0
-            _native.check(_native.lib().rag_comm_request_device(
-                self._comm, C.c_void_p(self._msg_host.data_ptr()) if leader else None,
-                C.c_void_p(self._msg_dev.data_ptr()), self._msg_bytes, 0,
-                None if leader else C.c_void_p(self._head_mirror.data_ptr()), self._req_seq, C.c_void_p(self._stream())))
+            from .flat_index import stream_wait
+            lib = _native.lib()
+            comm = self._req_comm if self._req_comm is not None else self._comm
+            rs = self._req_stream
+            st = rs.cuda_stream if rs is not None else self._stream()
+            _native.check(lib.rag_comm_request_device(
+                comm, C.c_void_p(msg.host.data_ptr()) if leader else None, C.c_void_p(msg.dev.data_ptr()),
+                self._msg_bytes, 0, None if leader else C.c_void_p(self._head_mirror.data_ptr()), self._req_seq,
+                C.c_void_p(st)))
             if leader:
-                self._msg_event.record()
-            return
+                if rs is not None:
+                    msg.event.record(rs)
+                else:
+                    msg.event.record()
+            else:   # the request's last kernel posts the head: poll one host word, no stream synchronisation
+                head_c = (C.c_int64 * 4)()
+                _native.check(lib.rag_comm_wait_head(C.c_void_p(self._head_mirror.data_ptr()), self._req_seq, -1, head_c))
+                self._last_head = tuple(int(v) for v in head_c)
+            if rs is not None:   # the search stream continues behind the message
+                stream_wait(self.device.index or 0, self._stream(), st)
+            return msg
         if self.backend == "nccl":
-            if self.rank == 0:
-                self._msg_dev.copy_(self._msg_host, non_blocking=True)  # the batch is uploaded once
-                self._msg_event.record()
-            dist.broadcast(self._msg_dev, src=0, group=self.group)
+            if leader:
+                msg.dev.copy_(msg.host, non_blocking=True)  # the batch is uploaded once
+                msg.event.record()
+            dist.broadcast(msg.dev, src=0, group=self.group)
+            if not leader:   # only the 32-byte head comes back to the host
+                self._head_pin.copy_(msg.dev[:HEAD_BYTES], non_blocking=True)
+                self._torch.cuda.current_stream(self.device).synchronize()
+                self._last_head = tuple(int(v) for v in self._head_pin.numpy().view(np.int64))
         else:
-            dist.broadcast(self._msg_host, src=0, group=self.group)
-            if self._msg_dev is not self._msg_host:
-                self._msg_dev.copy_(self._msg_host)
-
-    def _msg_free(self) -> None:
-        """Rank 0: the previous request's upload must have left the pinned message before it is refilled."""
-        if self._msg_event is not None and self.backend == "nccl":
-            self._msg_event.synchronize()
-
-    def _send_head(self, op: int, nq: int = 0, k: int = 0, d: int = 0) -> None:
-        self._msg_free()
-        self._msg_head_np[:] = (op, nq, k, d)
-        self._broadcast_msg()
-
-    def _fill_msg(self, q: np.ndarray) -> None:
-        """Rank 0: the batch into the pinned message (converting to fp32 if needed)."""
-        self._msg_free()
-        nq = q.shape[0]
-        self._msg_q_np[:nq * self.dim].reshape(nq, self.dim)[...] = q
+            dist.broadcast(msg.host, src=0, group=self.group)
+            if msg.dev is not msg.host:
+                msg.dev.copy_(msg.host)
+            if not leader:
+                self._last_head = tuple(int(v) for v in msg.head_np)
+        return msg
 
     def register_handler(self, op: int, fn: Callable[[], None]) -> None:
         """Followers: run `fn()` when the leader announces `op` (fn performs the matching collectives)."""
-        if op in (OP_SHUTDOWN, OP_SEARCH):
+        if op in (OP_SHUTDOWN, OP_SEARCH, OP_SEARCH_EXACT):
             raise ValueError(f"op {op} is reserved")
         self._handlers[int(op)] = fn
 
     def exclusive(self) -> Any:
-        """`with link.exclusive():` — hold the serving channel for one whole request: the message, every
-        collective that follows it and the read-back of the result.  leader_search() takes it itself;
-        a component that drives its own exchange through leader_call() (the reranker) wraps the
-        exchange in it."""
+        """`with link.exclusive():` — hold the serving channel for one whole exchange: the message and every
+        collective that follows it.  leader_search() takes it itself (around each request it enqueues, not around
+        the wait for the result); a component that drives its own exchange through leader_call() (the reranker)
+        wraps the exchange in it."""
         return self._lock
 
     def leader_call(self, op: int) -> None:
@@ -428,10 +468,43 @@ class ShardedFlatIndex:
         if self.rank != 0:
             raise RuntimeError("leader_call() is for rank 0")
         if self.world > 1:
-            self._send_head(int(op))
+            with self._lock:
+                self._request(int(op))
+
+    def _leader_enqueue(self, q: np.ndarray, k: int, exact: bool, slot: _Slot | None) -> _Slot:
+        """Rank 0, under the lock: one search request and its collective step, enqueued; returns its slot."""
+        nq = int(q.shape[0])
+        with self._cv:
+            if slot is None:
+                key = (nq, k)
+                while True:   # a free slot of this shape and room on the channel
+                    ring = self._slots.get(key)
+                    free = ring is None or ring[self._next[key]].pending is None
+                    if free and self._inflight < self.depth:
+                        break
+                    self._cv.wait()
+                slot = self._slot(nq, k)
+                slot.pending = q          # (taken: the device view of the queries replaces it below)
+                self._inflight += 1
+                fresh = True
+            else:
+                fresh = False
+            try:
+                msg = self._request(OP_SEARCH_EXACT if exact else OP_SEARCH, nq, k, self.dim, q)
+                slot.pending = msg.q_dev[:nq * self.dim].view(nq, self.dim)
+                self._step(slot, slot.pending, SEARCH_EXACT_ONE_PASS if exact else SEARCH_DEFER_FALLBACK)
+            except BaseException:
+                if fresh:   # (a repeat's slot is released by leader_search's own clean-up)
+                    slot.pending = None
+                    self._inflight -= 1
+                    self._cv.notify_all()
+                raise
+        return slot
 
     def leader_search(self, queries: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
-        """Rank 0: ship the batch in one broadcast, run the collective search, return the merged result."""
+        """Rank 0: ship the batch in one broadcast, run the collective search, return the merged result.  Thread-safe:
+        up to `depth` requests are in flight at once (the lock covers a request's enqueue, not the wait for its
+        result), so two pool threads keep the GPUs busy back to back."""
         if self.rank != 0:
             raise RuntimeError("leader_search() is for rank 0; other ranks run follower_loop()")
         q = np.asarray(queries)
@@ -440,52 +513,72 @@ class ShardedFlatIndex:
         nq_total, k = int(q.shape[0]), int(k)
         D = np.empty((nq_total, k), dtype=np.float32)
         I = np.empty((nq_total, k), dtype=np.int64)
-        with self._lock:
-            for lo in range(0, nq_total, self.max_batch):
-                nq = min(self.max_batch, nq_total - lo)
-                self._fill_msg(q[lo:lo + nq])
-                self._send_head(OP_SEARCH, nq, k, self.dim)
-                s = self.submit(self._msg_q_dev[:nq * self.dim].view(nq, self.dim), k)
-                self.collect(s)
+        for lo in range(0, nq_total, self.max_batch):
+            nq = min(self.max_batch, nq_total - lo)
+            s = self._leader_enqueue(q[lo:lo + nq], k, False, None)
+            try:
+                if s.event is not None:
+                    s.event.synchronize()
+                if int(s.host_any[0]) != 0:
+                    # some rank's certificate failed: the same batch again as an OP_SEARCH_EXACT request (the followers
+                    # do what they are told; they never look at a flag)
+                    self._leader_enqueue(q[lo:lo + nq], k, True, s)
+                    if s.event is not None:
+                        s.event.synchronize()
+                    s.repeats += 1
+                    self.repeats += 1
                 D[lo:lo + nq] = s.host_s.numpy()
                 I[lo:lo + nq] = s.host_i.numpy()
+            finally:
+                with self._cv:
+                    s.pending = None
+                    self._inflight -= 1
+                    self._cv.notify_all()
         return D, I
 
     def follower_loop(self) -> int:
-        """Ranks > 0: serve the leader's requests until it sends shutdown(); returns the number served."""
+        """Ranks > 0: serve the leader's requests until it sends shutdown(); returns the number served.  A search
+        request is enqueued and left to run — the next request is taken while it is still on the GPU."""
         if self.rank == 0:
             raise RuntimeError("follower_loop() is for ranks other than 0")
-        torch = self._torch
         served = 0
-        head_np = self._head_pin.numpy().view(np.int64) if self._head_pin is not None else self._msg_head_np
-        head_c = (C.c_int64 * 4)()
         while True:
-            self._broadcast_msg()
-            if self._comm is not None:   # the request's last kernel posts the head: poll one host word, no stream sync
-                from . import _native
-                _native.check(_native.lib().rag_comm_wait_head(C.c_void_p(self._head_mirror.data_ptr()), self._req_seq,
-                                                               -1, head_c))
-                head_np = np.frombuffer(head_c, dtype=np.int64)
-            elif self._head_pin is not None:  # only the 32-byte head comes back to the host
-                self._head_pin.copy_(self._msg_dev[:HEAD_BYTES], non_blocking=True)
-                torch.cuda.current_stream(self.device).synchronize()
-            op, nq, k, d = (int(v) for v in head_np)
-            if op == OP_SHUTDOWN:
-                return served
-            if op == OP_SEARCH:
-                if d != self.dim or not 0 < nq <= self.max_batch:
-                    raise RuntimeError(f"follower received a search of {nq} x {d}; this rank serves up to "
-                                       f"{self.max_batch} x {self.dim}")
-                with self._lock:
-                    self.collect(self.submit(self._msg_q_dev[:nq * d].view(nq, d), k))
-            elif op in self._handlers:
-                self._handlers[op]()
-            else:
-                raise RuntimeError(f"follower received op {op} with no handler registered")
+            with self._lock:
+                msg = self._request(OP_SHUTDOWN)   # (followers pass nothing: they receive)
+                op, nq, k, d = self._last_head
+                if op == OP_SHUTDOWN:
+                    if self.device.type == "cuda":
+                        self._torch.cuda.synchronize(self.device)
+                    return served
+                if op in (OP_SEARCH, OP_SEARCH_EXACT):
+                    if d != self.dim or not 0 < nq <= self.max_batch:
+                        raise RuntimeError(f"follower received a search of {nq} x {d}; this rank serves up to "
+                                           f"{self.max_batch} x {self.dim}")
+                    s = self._slot_for_follower(nq, k)
+                    self._step(s, msg.q_dev[:nq * d].view(nq, d),
+                               SEARCH_EXACT_ONE_PASS if op == OP_SEARCH_EXACT else SEARCH_DEFER_FALLBACK)
+                elif op in self._handlers:
+                    self._handlers[op]()
+                else:
+                    raise RuntimeError(f"follower received op {op} with no handler registered")
             served += 1
 
+    def _slot_for_follower(self, nq: int, k: int) -> _Slot:
+        """The next slot of the shape's ring, without the in-flight check: the leader bounds what is in flight, and a
+        slot's buffers are reused in stream order."""
+        key = (nq, k)
+        ring = self._slots.get(key)
+        if ring is None:
+            ring = self._slots[key] = [_Slot(self, nq, k) for _ in range(self.depth)]
+            self._next[key] = 0
+        i = self._next[key]
+        self._next[key] = (i + 1) % len(ring)
+        return ring[i]
+
     def shutdown(self) -> None:
-        """Rank 0: release the followers from follower_loop()."""
+        """Rank 0: release the followers from follower_loop() (after the requests in flight have finished)."""
         if self.rank == 0 and self.world > 1:
-            with self._lock:
-                self._send_head(OP_SHUTDOWN)
+            with self._cv:
+                while self._inflight:
+                    self._cv.wait()
+                self._request(OP_SHUTDOWN)

@@ -95,6 +95,40 @@ def make_pipelined(link):
     return step, drain
 
 
+def served_by_threads(link, n_threads=2):
+    """The product's situation: the scheduler has several batches in flight on pool threads of rank 0
+    (batch_scheduler.py:286-288); each thread calls leader_search back to back.  ms per batch over all threads."""
+    import threading
+    per_thread = max(1, steps // n_threads)
+
+    def client():
+        for _ in range(per_thread):
+            link.leader_search(Qh, k)
+
+    for _ in range(2):   # warm
+        link.leader_search(Qh, k)
+    torch.cuda.synchronize()
+    pool = [threading.Thread(target=client) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (per_thread * n_threads) * 1e3
+
+
+def host_costs(link, n=200):
+    """Host time of the two calls of a step, us: submit() (everything enqueued, nothing waited for) and collect()."""
+    ts, tc = [], []
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); s = link.submit(Q, k); t1 = time.perf_counter()
+        link.collect(s); t2 = time.perf_counter()
+        ts.append(t1 - t0); tc.append(t2 - t1)
+    return round(float(np.median(ts)) * 1e6, 1), round(float(np.median(tc)) * 1e6, 1)
+
+
 res = {"rows": rows, "dim": d, "batch": B, "k": k, "steps": steps, "world": 1, "backend": sh.backend,
        "collective": "own RCCL communicator inside the C ABI (rag_index_search_gather_device)"}
 ref = None
@@ -119,6 +153,10 @@ for mode in ("one_pass", "two_stage"):
     lead_p50, lead_p95 = percentiles(lambda: sh.leader_search(Qh, k))
     Dl, Il = sh.leader_search(Qh, k)
     lead_same = bool(np.array_equal(Il, ids) and np.array_equal(Dl.view(np.uint32), sc.view(np.uint32)))
+    served2 = served_by_threads(sh)
+    served2_over = served_by_threads(sh_over)
+    served2_torch = served_by_threads(sh_torch)
+    sub_us, col_us = host_costs(sh)
     host_ms, _ = timed(lambda: idx.search(Qh, k))   # one GPU, no group: what FAISSStore.search costs without sharding
     if ref is None:
         ref = (ids, sc)
@@ -126,8 +164,11 @@ for mode in ("one_pass", "two_stage"):
                  "scan_kernel_ms": round(scan_ms, 4),
                  "search_tensors_ms": round(sync_ms, 4), "pipelined_submit_collect_ms": round(pipe_ms, 4),
                  "pipelined_overlap_ms": round(over_ms, 4),
+                 "leader_search_two_threads_ms": round(served2, 4), "leader_search_two_threads_overlap_ms": round(served2_over, 4),
+                 "host_us": {"submit_call": sub_us, "collect_call_incl_gpu_wait": col_us},
                  "torch_collectives": {"search_tensors_ms": round(t_sync_ms, 4), "pipelined_submit_collect_ms": round(t_pipe_ms, 4),
-                                       "leader_search_ms": round(t_lead_ms, 4), "leader_search_p50_ms": round(t_lead_p50, 4)},
+                                       "leader_search_ms": round(t_lead_ms, 4), "leader_search_p50_ms": round(t_lead_p50, 4),
+                                       "leader_search_two_threads_ms": round(served2_torch, 4)},
                  "leader_search_ms": round(lead_ms, 4), "leader_search_p50_ms": round(lead_p50, 4),
                  "leader_search_p95_ms": round(lead_p95, 4), "rag_index_search_host_ms": round(host_ms, 4),
                  "scan_GBps": round((4.0 if mode == "one_pass" else 2.0) * rows * d / (scan_ms * 1e-3) / 1e9, 1),

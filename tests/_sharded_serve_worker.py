@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main() -> None:
     rank, world, port, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     threads = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    flagging = len(sys.argv) > 6 and sys.argv[6] == "flag"
     n, d = 3001, 32
     import torch
     import torch.distributed as dist
@@ -37,12 +38,25 @@ def main() -> None:
             np.ctypeslib.as_array(ctypes.cast(s_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, k_))[:] = D
             np.ctypeslib.as_array(ctypes.cast(i_ptr, ctypes.POINTER(ctypes.c_int64)), (nq_, k_))[:] = I
 
+    class FlaggingLocal(OracleLocal):
+        """rag_index_search_device_ex's contract: the LAST rank's deferred (two-stage) searches report "not final" and
+        leave garbage; the exact one-pass mode returns the truth with the word cleared."""
+
+        def search_device_ex(self, q_ptr, nq_, k_, s_ptr, i_ptr, mode_, flag_ptr, stream=0):
+            flag = np.ctypeslib.as_array(ctypes.cast(flag_ptr, ctypes.POINTER(ctypes.c_uint32)), (1,))
+            self.search_device(q_ptr, nq_, k_, s_ptr, i_ptr)
+            flag[0] = 0
+            if mode_ == 2 and rank == world - 1:  # SEARCH_DEFER_FALLBACK
+                np.ctypeslib.as_array(ctypes.cast(i_ptr, ctypes.POINTER(ctypes.c_int64)), (nq_, k_))[:] = 7
+                np.ctypeslib.as_array(ctypes.cast(s_ptr, ctypes.POINTER(ctypes.c_float)), (nq_, k_))[:] = 1e30
+                flag[0] = 1
+
     def merge(metric_, all_s, all_i, out_s, out_i):
         D, I = oracle.merge(all_s.numpy(), all_i.numpy(), metric_)
         out_s.copy_(torch.from_numpy(D))
         out_i.copy_(torch.from_numpy(I))
 
-    link = ShardedFlatIndex(OracleLocal(), 0, device="cpu", merge=merge, dim=d)
+    link = ShardedFlatIndex(FlaggingLocal() if flagging else OracleLocal(), 0, device="cpu", merge=merge, dim=d)
 
     class StubModel:  # score = 1 / (1 + tokens in the pair): deterministic, batch-shape independent
         class cfg:
@@ -92,7 +106,8 @@ def main() -> None:
                 th.start()
             for th in pool:
                 th.join()
-            np.savez(out_path, errors=np.array(errors, dtype=str), requests=2 * rounds * threads)
+            np.savez(out_path, errors=np.array(errors, dtype=str), requests=2 * rounds * threads + link.repeats,
+                     repeats=link.repeats)
             link.shutdown()
             dist.barrier()
             dist.destroy_process_group()
@@ -101,7 +116,7 @@ def main() -> None:
         shard = rr.rerank_batch(queries, docs, top_n=4)
         D1, I1 = link.leader_search(Q[:2], 3)
         same = all([(a.doc_id, a.score) for a in x] == [(b.doc_id, b.score) for b in y] for x, y in zip(local, shard))
-        np.savez(out_path, same=same, D0=D0, I0=I0, D1=D1, I1=I1)
+        np.savez(out_path, same=same, D0=D0, I0=I0, D1=D1, I1=I1, repeats=link.repeats)
         link.shutdown()
     else:
         rr.attach_shard_link(link)

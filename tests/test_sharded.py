@@ -91,10 +91,13 @@ def test_flagged_batches_are_repeated_through_the_exact_scan_on_every_rank(tmp_p
         assert int(res["repeats_pipelined"]) == 2 and int(res["repeats_total"]) == 2   # exactly the flagged ones
 
 
-def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
+@pytest.mark.parametrize("flagging", [False, True])
+def test_serving_channel_gloo_cpu_rehearsal(tmp_path, flagging):
     """Leader / follower protocol on CPU (world 3, gloo): searches and query-sharded rerank passes
     interleave on the channel, the sharded rerank equals the one-process result exactly (stub model),
-    shutdown releases the followers."""
+    shutdown releases the followers.  flagging: the last rank's two-stage searches report "not final" — the leader
+    re-sends each such batch as an OP_SEARCH_EXACT request (followers never look at a flag) and the answers are the
+    exact ones."""
     world, n, d = 3, 3001, 32
     port = _free_port()
     procs, outs = [], []
@@ -102,12 +105,13 @@ def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
         out = str(tmp_path / f"serve{r}.npz")
         outs.append(out)
         procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(HERE, "_sharded_serve_worker.py"), str(r), str(world), str(port), out],
+            [sys.executable, os.path.join(HERE, "_sharded_serve_worker.py"), str(r), str(world), str(port), out, "0",
+             "flag" if flagging else "plain"],
             env=dict(os.environ, OMP_NUM_THREADS="2")))
     for p in procs:
         assert p.wait(timeout=300) == 0
     lead = np.load(outs[0])
-    assert bool(lead["same"])
+    assert bool(lead["same"]) and int(lead["repeats"]) == (2 if flagging else 0)
     X, Q = oracle.synth_rows(1234, 0, n, d), oracle.synth_rows(4321, 0, 6, d)
     D0, I0 = oracle.search(X, Q, 5)
     D1, I1 = oracle.search(X, Q[:2], 3)
@@ -115,10 +119,11 @@ def test_serving_channel_gloo_cpu_rehearsal(tmp_path):
     np.testing.assert_array_equal(lead["D0"], D0)
     np.testing.assert_array_equal(lead["I1"], I1)
     np.testing.assert_array_equal(lead["D1"], D1)
-    assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])      # search, rerank, search
+    assert all(int(np.load(o)["served"]) == (5 if flagging else 3) for o in outs[1:])      # search, rerank, search (+ 2 repeats)
 
 
-def test_concurrent_batches_on_the_serving_channel(tmp_path):
+@pytest.mark.parametrize("flagging", [False, True])
+def test_concurrent_batches_on_the_serving_channel(tmp_path, flagging):
     """The scheduler runs batches concurrently on pool threads (reference batch_scheduler.py:286-288,
     retrieval/api.py:348-349): four threads on rank 0 issue searches (same and different shapes) and
     query-sharded rerank passes at once.  Each request's collectives must stay together — every answer
@@ -131,7 +136,7 @@ def test_concurrent_batches_on_the_serving_channel(tmp_path):
         outs.append(out)
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(HERE, "_sharded_serve_worker.py"), str(r), str(world), str(port), out,
-             str(threads)], env=dict(os.environ, OMP_NUM_THREADS="2")))
+             str(threads), "flag" if flagging else "plain"], env=dict(os.environ, OMP_NUM_THREADS="2")))
     try:
         for p in procs:
             assert p.wait(timeout=120) == 0
@@ -141,6 +146,7 @@ def test_concurrent_batches_on_the_serving_channel(tmp_path):
                 p.kill()
     lead = np.load(outs[0])
     assert lead["errors"].size == 0, lead["errors"].tolist()
+    assert (int(lead["repeats"]) > 0) == flagging
     assert all(int(np.load(o)["served"]) == int(lead["requests"]) for o in outs[1:])
 
 
