@@ -299,9 +299,29 @@ def main() -> None:
                 Dh, Ih = sharded.leader_search(Qh, k)
                 per.append(time.perf_counter() - t1)
             el = time.perf_counter() - t0
+            # the scheduler's situation (reference batch_scheduler.py:286-288): two batches in flight on pool threads of
+            # rank 0, each calling FAISSStore.search -> leader_search back to back
+            import threading
+            per_thread = max(1, args.steps // 2)
+
+            def client() -> None:
+                for _ in range(per_thread):
+                    sharded.leader_search(Qh, k)
+
+            pool = [threading.Thread(target=client) for _ in range(2)]
+            t2 = time.perf_counter()
+            for th in pool:
+                th.start()
+            for th in pool:
+                th.join()
+            el2 = time.perf_counter() - t2
             sharded.shutdown()
             out = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
                    "p50_latency_ms": float(np.median(per) * 1e3), "p95_latency_ms": float(np.percentile(per, 95) * 1e3),
+                   "two_batches_in_flight": {"value": B * 2 * per_thread / el2, "unit": "queries/s",
+                                             "ms_per_step": el2 / (2 * per_thread) * 1e3, "threads_on_rank_0": 2},
+                   "collective": ("own RCCL communicator inside the C ABI" if sharded.own_rccl else "torch.distributed")
+                                 + (", all-gather + merge and requests on their own streams" if sharded._comm_stream is not None else ""),
                    "steps": args.steps, "_D": Dh, "_I": Ih,
                    "path": f"ShardedFlatIndex.leader_search on rank 0, {world - 1} follower rank(s) in follower_loop: one "
                            f"{sharded._msg_bytes} B message per batch (one H2D, one broadcast), local search, one "

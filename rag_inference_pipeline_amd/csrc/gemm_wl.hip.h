@@ -69,12 +69,15 @@ __global__ void pack_f16_frag_kernel(const float* W, int N, int K, int ldw, _Flo
 constexpr float kX3Scale = 2048.0f;        // 2^11: the low plane is stored scaled so that it stays in fp16's normal range
 constexpr float kX3Unscale = 1.0f / 2048.0f;
 constexpr float kF16Max = 65504.0f;
-__global__ void pack_f16x2_frag_kernel(const float* W, int N, int K, int ldw, _Float16* out, uint32_t* range_flag) {
+// colscale (may be null): the image holds W[n][k] * colscale[k] — a LayerNorm's gamma folded into the GEMM that consumes
+// its output (see "LayerNorm folded into its consumers" below).
+__global__ void pack_f16x2_frag_kernel(const float* W, int N, int K, int ldw, _Float16* out, uint32_t* range_flag,
+                                       const float* colscale = nullptr) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)N * K) return;
     const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
     const int nt = n >> 5, r = n & 31, ks = k >> 4, h = (k >> 3) & 1, j = k & 7;
-    const float x = W[(size_t)n * ldw + k];
+    const float x = colscale ? W[(size_t)n * ldw + k] * colscale[k] : W[(size_t)n * ldw + k];
     if (range_flag && fabsf(x) >= kF16Max) *range_flag = 1u;   // (inf / huge: the caller keeps the split-bf16 image)
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)((x - (float)hi) * kX3Scale);
@@ -717,7 +720,66 @@ struct GemmWsParams {
     int k_per_split;        // K range of one split, multiple of 64; == K when not split
     int splits;             // the C slabs written: [splits][M][ldc]
     uint32_t* range_flag;
+    // ---- LayerNorm folded into its consumers (below); all null / 0 = the plain forms above
+    const float2* ts_in;    // [M][nblk_in] (mean, M2) of 32-column blocks of the rows whose LayerNorm is pending
+    int nblk_in;            // that LayerNorm's width / 32
+    float ln_eps;
+    const float* fold_s;    // form A: s[n] = sum_k W'[n][k] (W' = W gamma: the image), bias = b + W beta:
+                            //         C = act(rstd (acc - mean s[n]) + bias[n])
+    const float* Ry;        // form B: the residual BEFORE its LayerNorm, [M][ldr]: R = (Ry - mean) rstd ln_g[n] + ln_b[n]
+    const float* ln_g;
+    const float* ln_b;
+    float* Yout;            // form B: [M][ldc] the finished pre-LayerNorm rows (C holds the split-K slabs)
+    float2* ts_out;         // form B: [M][N / 32] (mean, M2) of the rows this GEMM writes (their LayerNorm is applied by
+                            //         whoever reads them next)
+    unsigned* tile_ctr;     // form B with split-K: one arrival counter per 64 x 64 NB output tile, zero between launches
 };
+
+// ---- LayerNorm folded into its consumers ------------------------------------------------------------------------------
+// The query encoder at batch 32 is a chain of ~85 dependent launches of 5-25 us; a quarter of them (24 of bge-base's)
+// were "sum the split-K slabs + bias + residual, LayerNorm" passes that do microseconds of work.  They are gone:
+//   * a GEMM that produces a layer's pre-LayerNorm sum y (attention output / feed-forward output projection, split-K)
+//     finishes itself: the LAST of a tile's K-splits to arrive (one atomic counter per tile; nobody waits for anybody)
+//     adds the slabs in split order, the bias and the residual, stores y, and leaves per row the (mean, M2) of each
+//     32-column block it holds — Chan's pairwise statistics, so no E[y^2] - E[y]^2 cancellation;
+//   * whoever reads y next applies the LayerNorm on the fly.  A GEMM whose INPUT is LN(y) (QKV, feed-forward input)
+//     runs on the raw y with gamma folded into its weight image: LN(y) W^T = rstd (y W'^T - mean s) + (b + W beta),
+//     W' = W gamma, s[n] = sum_k W'[n][k] — the K loop is untouched, the epilogue applies two per-row scalars;
+//   * a GEMM whose RESIDUAL is LN(y) recomputes it per element in its epilogue: (y - mean) rstd gamma[n] + beta[n].
+// Per row, mean and rstd come from combining the H / 32 block statistics (lnf_row_stats): ~50 loads per lane, issued
+// at the top of the epilogue.
+__device__ __forceinline__ void lnf_row_stats(const float2* ts, int nblk, float eps, float& mean, float& rstd) {
+    float sm = 0.f, sM2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float2 q = ts[b];
+        sm += q.x;
+        sM2 += q.y;
+    }
+    mean = sm / (float)nblk;
+    float dev = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float dl = ts[b].x - mean;
+        dev = __builtin_fmaf(dl, dl, dev);
+    }
+    rstd = rsqrtf((sM2 + 32.f * dev) / (32.f * (float)nblk) + eps);
+}
+
+// (mean, M2) of the 32 values of one row that lanes (r, 0) and (r, 1) hold between them, 16 each
+__device__ __forceinline__ float2 lnf_block_stats(const f32x16& v) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    const float m16 = s * (1.f / 16.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float dl = v[i] - m16;
+        m2 = __builtin_fmaf(dl, dl, m2);
+    }
+    const float om = __shfl_xor(m16, 32), om2 = __shfl_xor(m2, 32);
+    const float dm = m16 - om;
+    return make_float2(0.5f * (m16 + om), m2 + om2 + 8.f * dm * dm);   // n_a n_b / (n_a + n_b) = 8
+}
 
 __host__ __device__ inline int ws_grid(int M, int N, int NB, int splits) {
     const int mt = (M + 63) / 64, nct = (N + 64 * NB - 1) / (64 * NB);
@@ -849,10 +911,104 @@ __global__ __launch_bounds__((WsGeom<NB, KS_>::THREADS)) void gemm_nt_ws_kernel(
             for (int i = 0; i < 16; ++i) acc[b][i] += red[((((g - 1) * 4 + quad) * NB + b) * 16 + i) * 64 + lane];
     }
     float* Cz = p.C + (split ? (size_t)kz * p.M * p.ldc : 0);
+    const int m = m0 + wm * 32 + r;
+    if (!p.fold_s && !p.ts_out) {   // the plain forms
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-        store_tile_rows(acc[b], m0 + wm * 32 + r, n0 + (wn * NB + b) * 32, h, p.M, p.N, p.bias, p.R, p.ldr, Cz, p.ldc, p.act,
-                        split);
+        for (int b = 0; b < NB; ++b)
+            store_tile_rows(acc[b], m, n0 + (wn * NB + b) * 32, h, p.M, p.N, p.bias, p.R, p.ldr, Cz, p.ldc, p.act, split);
+        return;
+    }
+    // ---- LayerNorm folded into its consumers: this row's pending statistics
+    float mean = 0.f, rstd = 1.f;
+    if (p.ts_in && m < p.M) lnf_row_stats(p.ts_in + (size_t)m * p.nblk_in, p.nblk_in, p.ln_eps, mean, rstd);
+    if (p.fold_s) {   // form A: the input was LN(y), gamma is in the image: two per-row scalars finish it
+        if (m >= p.M) return;
+        const float ms = mean * rstd;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * NB + b) * 32 + 8 * g + 4 * h;
+                if (n >= p.N) continue;   // (N % 32 == 0: a float4 is inside or outside)
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.fold_s + n);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = apply_act(__builtin_fmaf(rstd, acc[b][4 * g + e], __builtin_fmaf(-ms, s4[e], b4[e])), p.act);
+                *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            }
+        return;
+    }
+    // form B: y = sum of the splits + bias + LN(Ry); the last split of the tile to arrive finishes it
+    if (split) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            store_tile_rows(acc[b], m, n0 + (wn * NB + b) * 32, h, p.M, p.N, nullptr, nullptr, 0, Cz, p.ldc, ACT_NONE, true);
+        __threadfence();                         // this thread's slab stores are visible device-wide ...
+        __syncthreads();                         // ... every (remaining) thread's are, and the ring is free
+        unsigned* word = reinterpret_cast<unsigned*>(smem + Geo::LDS - 16);
+        const int tile = (cz / p.splits) * mt + (unit % mt);
+        if (tid == 0) *word = atomicAdd(p.tile_ctr + tile, 1u);
+        __syncthreads();
+        if (*word != (unsigned)(p.splits - 1)) return;   // workgroup-uniform
+        __threadfence();                         // the other splits' slabs, as they were when their counts arrived
+        if (tid == 0) p.tile_ctr[tile] = 0u;     // ready for the next launch
+        if (m < p.M) {
+            // the slabs in split order, whoever came last; split z + 1's eight loads are in flight while split z is added
+            // (all of a lane's loads at once would take 8 x splits float4 registers)
+            f32x4 cur[NB][4], nxt[NB][4];
+            auto load_split = [&](f32x4 (&dst)[NB][4], int z) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + (wn * NB + b) * 32 + 8 * g + 4 * h;
+                        dst[b][g] = n < p.N ? *reinterpret_cast<const f32x4*>(p.C + ((size_t)z * p.M + m) * p.ldc + n)
+                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            };
+            load_split(cur, 0);
+            for (int z = 0; z < p.splits; ++z) {
+                if (z + 1 < p.splits) load_split(nxt, z + 1);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[b][4 * g + e] = z == 0 ? cur[b][g][e] : acc[b][4 * g + e] + cur[b][g][e];
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) cur[b][g] = nxt[b][g];
+            }
+        }
+    }
+    if (m >= p.M) return;
+    float* Y = p.Yout;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int nb0 = n0 + (wn * NB + b) * 32;
+        if (nb0 >= p.N) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nb0 + 8 * g + 4 * h;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.Ry + (size_t)m * p.ldr + n);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.ln_g + n);
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (acc[b][4 * g + e] + b4[e]) + __builtin_fmaf((y4[e] - mean) * rstd, g4[e], e4[e]);
+                acc[b][4 * g + e] = v[e];
+            }
+            *reinterpret_cast<f32x4*>(Y + (size_t)m * p.ldc + n) = v;
+        }
+        const float2 st = lnf_block_stats(acc[b]);
+        if (h == 0) p.ts_out[(size_t)m * (p.N >> 5) + (nb0 >> 5)] = st;
+    }
 }
 
 }  // namespace ragb

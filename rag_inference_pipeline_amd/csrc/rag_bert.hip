@@ -52,6 +52,15 @@ struct rag_bert {
     std::vector<_Float16*> wx2;
     std::vector<__bf16*> wx;
     std::vector<_Float16*> wxf;
+    // LayerNorm folded into its consumers (gemm_wl.hip.h; query-encoder path, <= 1024 tokens): per layer the two-plane
+    // images of the QKV and feed-forward input weights with the preceding LayerNorm's gamma folded in, and for each the
+    // vectors s[n] = sum_k W'[n][k] and bias2 = bias + W beta.  Built at create when the model qualifies (lnf_ok).
+    std::vector<_Float16*> wfold;     // [2 l] QKV, [2 l + 1] feed-forward input
+    std::vector<float*> fold_s, fold_b;
+    bool lnf_ok = false;
+    float* y1 = nullptr;              // [ws_tokens][H]: the second pre-LayerNorm row buffer (x is the first)
+    float2 *ts_a = nullptr, *ts_b = nullptr;   // [ws_tokens][H / 32] block statistics of x / y1
+    unsigned* tile_ctr = nullptr;     // arrival counters of the split-K tiles (zero between launches)
     uint32_t* range_pin = nullptr;    // pinned host word the GEMM kernels write themselves (posted store): a two-plane
                                       // GEMM met |a| >= 65504 (or a weight did, at creation); read after a sync
     bool weights_fit_f16 = true;      // every GEMM weight is inside fp16's range: the two-plane images are valid
@@ -136,11 +145,14 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
         ++h->ws_generation;
     }
     if (tokens > h->ws_tokens) {
-        float** bufs[] = {&h->x, &h->y, &h->qkv, &h->ctx, &h->ffn};
+        float** bufs[] = {&h->x, &h->y, &h->qkv, &h->ctx, &h->ffn, &h->y1};
         for (float** b : bufs) {
             if (*b) (void)hipFree(*b);
             *b = nullptr;
         }
+        if (h->ts_a) (void)hipFree(h->ts_a);
+        if (h->ts_b) (void)hipFree(h->ts_b);
+        h->ts_a = h->ts_b = nullptr;
         h->ws_tokens = 0;
         const long long t = (tokens + tokens / 8 + 31) & ~31LL;   // (whole 32-token row blocks: the tiled layout's unit)
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->x), (size_t)t * c.hidden * sizeof(float)));
@@ -149,6 +161,12 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qkv), (size_t)t * 3 * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ctx), (size_t)t * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ffn), (size_t)t * c.intermediate * sizeof(float)));
+        if (h->lnf_ok) {
+            const long long ts_rows = std::min<long long>(t, 1056);   // the folded-LayerNorm path takes <= 1024 tokens
+            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y1), (size_t)ts_rows * c.hidden * sizeof(float)));
+            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_a), (size_t)ts_rows * (c.hidden / 32) * sizeof(float2)));
+            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_b), (size_t)ts_rows * (c.hidden / 32) * sizeof(float2)));
+        }
         h->ws_tokens = t;
     }
     if (nseq > h->ws_seqs) {
@@ -379,6 +397,42 @@ int launch_gemm_ln(const float* A, int lda, const WRef& Wr, int ldw, const float
     return RAG_OK;
 }
 
+// ---- LayerNorm folded into its consumers (gemm_wl.hip.h): the two GEMM forms of the query-encoder path ----------------
+// Form A: C = act(LN(y) W^T + b) computed as act(rstd (y W'^T - mean s) + b2) — A = y raw, image W' = W gamma.
+int launch_ws_lnf_a(rag_bert* h, const float* Y, const float2* ts_in, const _Float16* img, const float* s_vec, const float* b2,
+                    float* C, int M, int N, int K, int act, uint32_t* range_flag, hipStream_t st) {
+    ragb::GemmWsParams g{Y, img, b2, nullptr, C, M, N, K, K, 0, N, act, K, 1, range_flag};
+    g.ts_in = ts_in;
+    g.nblk_in = K / 32;
+    g.ln_eps = h->cfg.ln_eps;
+    g.fold_s = s_vec;
+    return launch_ws(g, 1, h->n_cus, st, h->background);
+}
+
+// Form B: Yout = A W^T + b + LN(Ry), split-K finished by the last split of a tile to arrive; leaves Yout's block statistics.
+constexpr int kLnfMaxTiles = 4096;
+int launch_ws_lnf_b(rag_bert* h, const float* A, int K, const _Float16* img, const float* bias, const float* Ry,
+                    const float2* ts_in, const float* ln_g, const float* ln_b, float* Yout, float2* ts_out, int M, int N,
+                    uint32_t* range_flag, hipStream_t st) {
+    // split K while that still adds workgroups to an under-filled chip (as launch_gemm_ln)
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    int sp = 1;
+    for (int c = 2; c <= kMaxSplits; ++c)
+        if (K % (64 * c) == 0 && K / c >= 128 && tiles * c <= h->n_cus) sp = c;
+    if (tiles > kLnfMaxTiles) return ragc_fail(RAG_ERR_UNSUPPORTED, "too many output tiles for the arrival counters");
+    ragb::GemmWsParams g{A, img, bias, nullptr, h->y, M, N, K, K, N, N, ragb::ACT_NONE, K / sp, sp, range_flag};
+    g.ts_in = ts_in;
+    g.nblk_in = N / 32;      // the residual's LayerNorm is as wide as this GEMM's output (N == H)
+    g.ln_eps = h->cfg.ln_eps;
+    g.Ry = Ry;
+    g.ln_g = ln_g;
+    g.ln_b = ln_b;
+    g.Yout = Yout;
+    g.ts_out = ts_out;
+    g.tile_ctr = h->tile_ctr;
+    return launch_ws(g, sp, h->n_cus, st, h->background);
+}
+
 size_t out_elems(const rag_bert_config& c, int out_kind, long long nseq, long long tokens) {
     switch (out_kind) {
         case RAG_BERT_OUT_MEAN:
@@ -457,16 +511,75 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         else if (H <= 768) hipLaunchKernelGGL((ln_tiled_kernel<half_t, 12>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
         else hipLaunchKernelGGL((ln_tiled_kernel<half_t, 16>), dim3(nrb), dim3(256), 0, st, src, g, b, dst, T, H, c.ln_eps);
     };
+    // The query-encoder path (<= 1024 tokens, two-plane images valid): LayerNorms folded into their consumers — five
+    // launches per layer instead of seven (gemm_wl.hip.h).  x holds the layer's PRE-LayerNorm input, ts_a its statistics.
+    const bool lnf = h->lnf_ok && T <= 1024 && T <= h->ws_tokens && !h->force_x6 && !h->valu_attention && !tiled &&
+                     h->weights_fit_f16 && h->ts_a != nullptr;
+    const float* xfinal = h->x;   // what the output stage reads as the last hidden state
     if (tiled) {
         if (H <= 384) hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 6>), dim3(nrb), dim3(256), 0, st, ep, xh);
         else if (H <= 768) hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 12>), dim3(nrb), dim3(256), 0, st, ep, xh);
         else hipLaunchKernelGGL((embed_ln_tiled_kernel<half_t, 16>), dim3(nrb), dim3(256), 0, st, ep, xh);
+    } else if (lnf) {
+        embed_pre_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep, h->ts_a);
     } else {
         embed_ln_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(ep);
     }
     RAGC_HIP_TRY(hipGetLastError());
 
-    for (int l = 0; l < c.n_layers; ++l) {
+    for (int l = 0; lnf && l < c.n_layers; ++l) {
+        const float* const* lw = w + kEmbEntries + kPerLayer * l;
+        const float* g_prev = l == 0 ? w[3] : (lw - kPerLayer)[10];   // the LayerNorm pending on x
+        const float* b_prev = l == 0 ? w[4] : (lw - kPerLayer)[11];
+        const size_t at = (size_t)4 * l;
+        const bool last_first_only = first_only_out && l == c.n_layers - 1 && nseq < T;
+        rc = launch_ws_lnf_a(h, h->x, h->ts_a, h->wfold[2 * l], h->fold_s[2 * l], h->fold_b[2 * l], h->qkv, T, 3 * H, H, ACT_NONE,
+                             range_flag, st);
+        if (rc) return rc;
+        if (last_first_only) {
+            // the rest of this layer runs on the sequences' first rows only, with materialised LayerNorms (nseq rows)
+            const dim3 fgrid(1, heads, nseq);
+            if (dh == 32)
+                attention_mfma_kernel<32><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
+            else
+                attention_mfma_kernel<64><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
+            RAGC_HIP_TRY(hipGetLastError());
+            gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps);
+            RAGC_HIP_TRY(hipGetLastError());
+            const WRef w1{lw[2], h->wx2[at + 1], nullptr, nullptr, range_flag, h->background};
+            const WRef w2{lw[6], h->wx2[at + 2], nullptr, nullptr, range_flag, h->background};
+            const WRef w3{lw[8], h->wx2[at + 3], nullptr, nullptr, range_flag, h->background};
+            rc = launch_gemm_ln(h->ctx, H, w1, H, lw[3], h->pooled, h->y, lw[4], lw[5], h->pooled, nseq, H, H, c.ln_eps, h->n_cus, st);
+            if (rc) return rc;
+            rc = launch_gemm(h->pooled, H, w2, H, lw[7], nullptr, 0, h->ffn, I, nseq, I, H, act, st, h->n_cus);
+            if (rc) return rc;
+            rc = launch_gemm_ln(h->ffn, I, w3, I, lw[9], h->pooled, h->y, lw[10], lw[11], h->pooled, nseq, H, I, c.ln_eps, h->n_cus, st);
+            if (rc) return rc;
+            compact = true;
+            break;
+        }
+        if (dh == 32)
+            attention_mfma_kernel<32><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        else
+            attention_mfma_kernel<64><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        RAGC_HIP_TRY(hipGetLastError());
+        // y1 = ctx Wo^T + bo + LN_prev(x): finished by the last K-split of each tile; statistics to ts_b
+        rc = launch_ws_lnf_b(h, h->ctx, H, h->wx2[at + 1], lw[3], h->x, h->ts_a, g_prev, b_prev, h->y1, h->ts_b, T, H, range_flag, st);
+        if (rc) return rc;
+        rc = launch_ws_lnf_a(h, h->y1, h->ts_b, h->wfold[2 * l + 1], h->fold_s[2 * l + 1], h->fold_b[2 * l + 1], h->ffn, T, I, H, act,
+                             range_flag, st);
+        if (rc) return rc;
+        // x = ffn W2^T + b2 + LN1(y1): the next layer's pre-LayerNorm input; statistics to ts_a
+        rc = launch_ws_lnf_b(h, h->ffn, I, h->wx2[at + 3], lw[9], h->y1, h->ts_b, lw[4], lw[5], h->x, h->ts_a, T, H, range_flag, st);
+        if (rc) return rc;
+        if (l == c.n_layers - 1) {   // the encoder's last LayerNorm, materialised once for the output stage
+            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y1, T, H, c.ln_eps);
+            RAGC_HIP_TRY(hipGetLastError());
+            xfinal = h->y1;
+        }
+    }
+
+    for (int l = 0; !lnf && l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
         const int wsrc[4] = {0, 2, 6, 8};  // qkv_w, attn_out_w, ffn_in_w, ffn_out_w in the layer's table
         auto wref = [&](int i) -> WRef {
@@ -583,7 +696,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 RAGC_HIP_TRY(hipGetLastError());
                 break;
             }
-            RAGC_HIP_TRY(hipMemcpyAsync(out, h->x, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+            RAGC_HIP_TRY(hipMemcpyAsync(out, xfinal, (size_t)T * H * sizeof(float), hipMemcpyDeviceToDevice, st));
             break;
         case RAG_BERT_OUT_MEAN:
         case RAG_BERT_OUT_CLS:
@@ -592,7 +705,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             else if (tiled)
                 pool_tiled_kernel<half_t><<<dim3(nseq), dim3(256), 0, st>>>(xh, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
             else
-                pool_kernel<<<dim3(nseq), dim3(256), 0, st>>>(h->x, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
+                pool_kernel<<<dim3(nseq), dim3(256), 0, st>>>(xfinal, cu, out, H, out_kind == RAG_BERT_OUT_MEAN ? 0 : 1, normalize);
             RAGC_HIP_TRY(hipGetLastError());
             break;
         case RAG_BERT_OUT_LOGITS:
@@ -603,7 +716,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 if (tiled)
                     gather_rows_tiled_kernel<half_t><<<dim3((total + 255) / 256), dim3(256), 0, st>>>(xh, cu, h->pooled, nseq, H);
                 else
-                    gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
+                    gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(xfinal, cu, h->pooled, nseq, H);
                 RAGC_HIP_TRY(hipGetLastError());
             }
             rc = launch_gemm(h->pooled, H, WRef{hw[0], nullptr, nullptr, nullptr, nullptr, false}, H, hw[1], nullptr, 0, h->pooled2, H, nseq, H, H, ACT_TANH, st);
@@ -672,6 +785,57 @@ int build_images(rag_bert* h, int kind) {
 }
 }  // namespace
 
+
+namespace {
+// LayerNorm folded into its consumers (gemm_wl.hip.h): per layer, the QKV and feed-forward input weights with the
+// preceding LayerNorm's gamma folded into their two-plane images, plus s[n] = sum_k W'[n][k] and bias2 = bias + W beta.
+// Models whose widths the small-batch kernel does not take (K % 64, N % 32) keep the separate LayerNorm launches.
+int build_folded(rag_bert* h) {
+    const rag_bert_config& c = h->cfg;
+    const int H = c.hidden, I = c.intermediate;
+    if (H % 64 || I % 64 || h->wx2.empty()) return RAG_OK;
+    const size_t n = (size_t)2 * c.n_layers;
+    h->wfold.assign(n, nullptr);
+    h->fold_s.assign(n, nullptr);
+    h->fold_b.assign(n, nullptr);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const float* const* lw = h->w.data() + kEmbEntries + kPerLayer * l;
+        const float* g_prev = l == 0 ? h->w[3] : (lw - kPerLayer)[10];
+        const float* b_prev = l == 0 ? h->w[4] : (lw - kPerLayer)[11];
+        const struct { const float *W, *bias, *g, *b; int N; } jobs[2] = {{lw[0], lw[1], g_prev, b_prev, 3 * H},
+                                                                         {lw[6], lw[7], lw[4], lw[5], I}};
+        for (int j = 0; j < 2; ++j) {
+            const size_t at = (size_t)2 * l + j;
+            const int N = jobs[j].N, K = H;
+            void* img = nullptr;
+            float *sv = nullptr, *bv = nullptr;
+            if (hipMalloc(&img, (size_t)N * K * 4) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&sv), (size_t)N * sizeof(float)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&bv), (size_t)N * sizeof(float)) != hipSuccess) {
+                if (img) (void)hipFree(img);
+                if (sv) (void)hipFree(sv);
+                return ragc_fail(RAG_ERR_OOM, "device allocation of the LayerNorm-folded weight images failed");
+            }
+            h->wfold[at] = static_cast<_Float16*>(img);
+            h->fold_s[at] = sv;
+            h->fold_b[at] = bv;
+            ragb::pack_f16x2_frag_kernel<<<dim3((unsigned)(((long long)N * K + 255) / 256)), dim3(256), 0, h->stream>>>(
+                jobs[j].W, N, K, K, h->wfold[at], h->range_pin, jobs[j].g);
+            ragb::fold_prep_kernel<<<dim3((N + 3) / 4), dim3(256), 0, h->stream>>>(jobs[j].W, jobs[j].bias, jobs[j].g, jobs[j].b, N, K, sv, bv);
+        }
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&h->tile_ctr), kLnfMaxTiles * sizeof(unsigned)) != hipSuccess)
+        return ragc_fail(RAG_ERR_OOM, "device allocation of the tile counters failed");
+    if (hipMemsetAsync(h->tile_ctr, 0, kLnfMaxTiles * sizeof(unsigned), h->stream) != hipSuccess || hipGetLastError() != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+        return ragc_fail(RAG_ERR_HIP, "building the LayerNorm-folded weight images failed");
+    if (*h->range_pin) {   // a folded weight (W gamma) outside fp16's range: keep the separate LayerNorm launches
+        *h->range_pin = 0;
+        return RAG_OK;
+    }
+    h->lnf_ok = true;
+    return RAG_OK;
+}
+}  // namespace
 
 namespace {
 
@@ -908,6 +1072,13 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
             }
         }
     }
+    if (c.gemm_mode == RAG_GEMM_F32 && h->weights_fit_f16) {
+        const char* lf = getenv("RAG_AMD_ENCODER_LN_FOLD");   // =0: keep the separate LayerNorm launches (A/B checks)
+        if (!(lf && *lf == '0') && (rc = build_folded(h))) {
+            rag_bert_destroy(h);
+            return rc;
+        }
+    }
     *out = h;
     return RAG_OK;
 }
@@ -927,6 +1098,15 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
         for (_Float16* p : h->wx2)
             if (p) (void)hipFree(p);
         for (_Float16* p : h->wxf)
+            if (p) (void)hipFree(p);
+        for (_Float16* p : h->wfold)
+            if (p) (void)hipFree(p);
+        for (float* p : h->fold_s)
+            if (p) (void)hipFree(p);
+        for (float* p : h->fold_b)
+            if (p) (void)hipFree(p);
+        void* lptrs[] = {h->y1, h->ts_a, h->ts_b, h->tile_ctr};
+        for (void* p : lptrs)
             if (p) (void)hipFree(p);
         for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
         void* gptrs[] = {h->g_blk, h->g_out, h->g_flag};

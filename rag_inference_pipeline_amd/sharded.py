@@ -197,8 +197,8 @@ class ShardedFlatIndex:
             self._comm = self._create_comm()
             if self._comm is not None:
                 self._head_mirror = torch.zeros(8 * 5, dtype=torch.uint8).pin_memory()
-        if overlap_collective is None:   # from the environment: only where there is a collective to overlap
-            overlap_collective = os.environ.get("RAG_AMD_COMM_OVERLAP", "0") == "1" and self.world > 1
+        if overlap_collective is None:   # the default wherever there is a collective to overlap; RAG_AMD_COMM_OVERLAP=0 turns it off
+            overlap_collective = os.environ.get("RAG_AMD_COMM_OVERLAP", "1") != "0" and self.world > 1
         if overlap_collective and self._comm is not None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
             self._req_comm = self._create_comm()

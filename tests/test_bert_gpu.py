@@ -372,6 +372,53 @@ def test_query_encoder_replays_a_graph_per_padded_shape(gpu_required, monkeypatc
     eager.close()
 
 
+@pytest.mark.parametrize("arch", ["minilm", "bge", "cross"])
+def test_layernorms_folded_into_their_consumers_match_the_separate_launches(gpu_required, monkeypatch, arch):
+    """The query-encoder path (<= 1024 tokens) has no LayerNorm launches: the GEMM that produces a layer's pre-LayerNorm
+    sum finishes its own split-K reduction (last split of a tile to arrive) and leaves block statistics, the GEMMs that
+    read it apply the LayerNorm in their epilogue (gamma folded into the weight image) or recompute the residual from
+    it.  Same values as the separate-launch form (RAG_AMD_ENCODER_LN_FOLD=0) and as the oracle, on token counts around
+    the 64-row tile boundaries, one-token batches, the graph replay path, and after several back-to-back passes (the
+    arrival counters reset themselves)."""
+    if arch == "minilm":
+        cfg = _small(BertConfig.minilm_l6())
+    elif arch == "bge":
+        cfg = _small(BertConfig.bge_base())
+        cfg.n_layers = 3
+    else:
+        cfg = _small(BertConfig.ms_marco_minilm_l6())
+    w = random_weights(cfg, 91)
+    for key in list(w):   # LayerNorm parameters away from (1, 0), so that folding them is actually exercised
+        if key.endswith("_g"):
+            w[key] = (w[key] * np.linspace(0.5, 1.5, w[key].size, dtype=np.float32)).astype(np.float32)
+        elif key.endswith("ln1_b") or key.endswith("ln2_b") or key == "emb_ln_b":
+            w[key] = (w[key] + np.linspace(-0.3, 0.3, w[key].size, dtype=np.float32)).astype(np.float32)
+    folded = BertModel(cfg, w)
+    monkeypatch.setenv("RAG_AMD_ENCODER_LN_FOLD", "0")
+    plain = BertModel(cfg, w)
+    monkeypatch.delenv("RAG_AMD_ENCODER_LN_FOLD")
+    rng = np.random.default_rng(91)
+    cases = [[1], [2, 1], [63], [64], [65], [8] * 16, rng.integers(8, 21, size=32).tolist(), [100, 28], [120] * 8 + [57],
+             rng.integers(8, 21, size=32).tolist()]
+    for lens in cases:
+        seqs = _seqs(rng, lens, cfg.vocab_size)
+        types = [[0] * (len(q) // 2) + [1] * (len(q) - len(q) // 2) for q in seqs]
+        if arch == "cross":
+            got, ref = folded.classify(seqs, types, sigmoid=False), plain.classify(seqs, types, sigmoid=False)
+            np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+            np.testing.assert_allclose(got, obert.classify(cfg, w, seqs, types, sigmoid=False), atol=1e-4, rtol=1e-4)
+            continue
+        hid, hid_ref = folded.hidden_states(seqs, types), plain.hidden_states(seqs, types)
+        np.testing.assert_allclose(hid, hid_ref, atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(hid, np.concatenate(obert.hidden_states(cfg, w, seqs, types)), atol=5e-5, rtol=1e-4)
+        emb = folded.embed(seqs, types)
+        np.testing.assert_allclose(emb, plain.embed(seqs, types), atol=3e-6, rtol=1e-5)
+        np.testing.assert_allclose(emb, obert.embed(cfg, w, seqs, types), atol=1e-5)
+        np.testing.assert_allclose(folded.embed_to_device(seqs, types).numpy(), emb, atol=3e-6, rtol=1e-5)   # graph replay
+    folded.close()
+    plain.close()
+
+
 def test_cached_encoder_graphs_survive_a_workspace_reallocation(gpu_required, monkeypatch):
     """A cached graph holds the activation workspace's addresses.  A later pass that needs a bigger workspace — an eager
     embed() of more tokens than the graph path ever takes — frees and reallocates those buffers; the next replay of the
