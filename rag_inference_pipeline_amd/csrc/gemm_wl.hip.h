@@ -942,20 +942,34 @@ __global__ __launch_bounds__((WsGeom<NB, KS_>::THREADS)) void gemm_nt_ws_kernel(
     }
     // form B: y = sum of the splits + bias + LN(Ry); the last split of the tile to arrive finishes it
     if (split) {
+        // The slabs cross workgroups INSIDE a launch, and a device-scope fence is not the way: on this chip each XCD has
+        // its own L2, so `__threadfence()` compiles to a write-back of the whole L2 (buffer_wbl2) and an invalidate — with
+        // 252 workgroups doing that, a 7 us GEMM took 45 (measured).  Instead the slab words themselves are written and
+        // read at agent scope (relaxed atomic stores / loads: plain global_store / global_load with the sc1 bit, served
+        // by the memory side where all XCDs agree), and a workgroup-scope release (a wait for this wave's stores) in
+        // front of the barrier orders them before the arrival count.
+        if (m < p.M) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            store_tile_rows(acc[b], m, n0 + (wn * NB + b) * 32, h, p.M, p.N, nullptr, nullptr, 0, Cz, p.ldc, ACT_NONE, true);
-        __threadfence();                         // this thread's slab stores are visible device-wide ...
-        __syncthreads();                         // ... every (remaining) thread's are, and the ring is free
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + (wn * NB + b) * 32 + 8 * g + 4 * h;
+                    if (n >= p.N) continue;
+                    float* dst = Cz + (size_t)m * p.ldc + n;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, acc[b][4 * g + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's slab stores have completed ...
+        __syncthreads();                                         // ... every (remaining) wave's have, and the ring is free
         unsigned* word = reinterpret_cast<unsigned*>(smem + Geo::LDS - 16);
         const int tile = (cz / p.splits) * mt + (unit % mt);
-        if (tid == 0) *word = atomicAdd(p.tile_ctr + tile, 1u);
+        if (tid == 0) *word = __hip_atomic_fetch_add(p.tile_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*word != (unsigned)(p.splits - 1)) return;   // workgroup-uniform
-        __threadfence();                         // the other splits' slabs, as they were when their counts arrived
-        if (tid == 0) p.tile_ctr[tile] = 0u;     // ready for the next launch
+        if (tid == 0) __hip_atomic_store(p.tile_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
         if (m < p.M) {
-            // the slabs in split order, whoever came last; split z + 1's eight loads are in flight while split z is added
+            // the slabs in split order, whoever came last; split z + 1's loads are in flight while split z is added
             // (all of a lane's loads at once would take 8 x splits float4 registers)
             f32x4 cur[NB][4], nxt[NB][4];
             auto load_split = [&](f32x4 (&dst)[NB][4], int z) {
@@ -964,8 +978,9 @@ __global__ __launch_bounds__((WsGeom<NB, KS_>::THREADS)) void gemm_nt_ws_kernel(
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int n = n0 + (wn * NB + b) * 32 + 8 * g + 4 * h;
-                        dst[b][g] = n < p.N ? *reinterpret_cast<const f32x4*>(p.C + ((size_t)z * p.M + m) * p.ldc + n)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const float* src = p.C + ((size_t)z * p.M + m) * p.ldc + (n < p.N ? n : 0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dst[b][g][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
             };
             load_split(cur, 0);

@@ -1073,8 +1073,12 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
         }
     }
     if (c.gemm_mode == RAG_GEMM_F32 && h->weights_fit_f16) {
-        const char* lf = getenv("RAG_AMD_ENCODER_LN_FOLD");   // =0: keep the separate LayerNorm launches (A/B checks)
-        if (!(lf && *lf == '0') && (rc = build_folded(h))) {
+        // Measured slower and therefore OFF unless asked for (RAG_AMD_ENCODER_LN_FOLD=1): handing a tile's slabs from one
+        // workgroup to another inside a launch costs two to three memory-side round trips (agent-scope stores, the arrival
+        // atomic, agent-scope loads: 10-19 us per GEMM) — more than the kernel boundary and the 6 us LayerNorm launch it
+        // replaces (bge-base, 32 queries: 1.37 ms folded against 1.00 ms).
+        const char* lf = getenv("RAG_AMD_ENCODER_LN_FOLD");
+        if (lf && *lf == '1' && (rc = build_folded(h))) {
             rag_bert_destroy(h);
             return rc;
         }
