@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 4
+#define RAG_AMD_ABI_VERSION 5
 
 /* status codes */
 #define RAG_OK 0
@@ -247,6 +247,37 @@ int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t
                                          float* out_scores_dev, int64_t* out_ids_dev, uint32_t* any_flag_dev,
                                          void* host_mirror, void* stream);
 
+
+/* ---- IVFFlat `nprobe` mode (optional) --------------------------------------------------------------------- */
+
+/* The reference's data generator writes a faiss IndexIVFFlat (scripts/create_test_docs.py:83-104: L2, nlist 4096,
+ * nprobe 64) and FAISSStore.load sets index.nprobe from the settings (faiss_store.py:84-92): on such a file
+ * index.search (faiss_store.py:152) looks only at the rows of the `nprobe` inverted lists whose centroids are
+ * nearest to the query.  rag_index_* answers such a file exhaustively (every list: more exact than the reference);
+ * rag_ivf_* restates the reference's candidate set:
+ *   1. coarse quantizer: the flat scan (rag_index machinery) over the nlist centroids, nprobe best per query under the
+ *      quantizer's metric, ties by ascending list number;
+ *   2. every (query, probed list) pair scans its list with the canonical dot product of the flat search;
+ *   3. the query's nprobe per-list top-k lists are merged: (score, then ascending stored id).
+ * faiss ranks equal scores by its heap's visiting order; here the rule is the flat search's.  With nprobe >= nlist the
+ * result equals rag_index_search's bit for bit.  k <= 256.  Parity status: as the flat search (unpinned against faiss
+ * itself; held to oracle/flat.py:ivf_search). */
+typedef struct rag_ivf rag_ivf;
+int rag_ivf_create(int32_t d, int32_t metric, int32_t quantizer_metric, int32_t device, rag_ivf** out);
+int rag_ivf_destroy(rag_ivf* h);
+
+/* The trained index, once: nlist centroids (nlist x d fp32), the rows in LIST order (list l owns rows
+ * list_offsets[l] .. list_offsets[l + 1] - 1 of rows_host / ids_host; list_offsets has nlist + 1 entries, from 0 to
+ * ntotal) and each row's stored id (what a search returns; 0 <= id <= 2^32 - 2).  Host pointers; blocks. */
+int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_t nlist, const float* rows_host,
+                      const int64_t* ids_host, const int64_t* list_offsets_host);
+int64_t rag_ivf_ntotal(const rag_ivf* h);
+int64_t rag_ivf_nlist(const rag_ivf* h);
+
+/* index.search(embeddings, k) with index.nprobe = nprobe (clamped to nlist).  Same output conventions as
+ * rag_index_search (-1 / -+FLT_MAX padding when fewer than k rows are reachable).  Host pointers; blocks. */
+int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k, int32_t nprobe, float* out_scores,
+                   int64_t* out_ids);
 
 /* ---- C1: the shard step's collectives on an own RCCL communicator (SURVEY §8a "C1", §8e) ------------------- */
 

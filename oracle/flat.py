@@ -103,6 +103,35 @@ def merge(scores_: np.ndarray, ids: np.ndarray, metric: int = METRIC_IP) -> tupl
     return D, I
 
 
+def ivf_search(centroids: np.ndarray, quantizer_metric: int, rows: np.ndarray, ids: np.ndarray, offsets: np.ndarray,
+               Q: np.ndarray, k: int, nprobe: int, metric: int = METRIC_L2) -> tuple[np.ndarray, np.ndarray]:
+    """Oracle of the IVFFlat `nprobe` mode (faiss IndexIVF::search as the reference uses it: index.nprobe set at load,
+    faiss_store.py:84-92; index.search, faiss_store.py:152; file written by scripts/create_test_docs.py:83-104).
+      1. quantizer.search(Q, nprobe): the flat oracle over the centroids under the quantizer's metric;
+      2. per query, the candidates are the rows of those lists (`rows` / `ids` in list order, list l =
+         [offsets[l], offsets[l + 1]));
+      3. exact top-k of the candidates with the flat oracle's canonical score, ranked (score, ascending stored id).
+    faiss leaves the order among equal scores to its heap's visiting order; the candidate set is what nprobe defines.
+    Parity status: unpinned against faiss itself, like the flat oracle.  Pure numpy over rago_search; small cases."""
+    centroids, rows, Q = _f32(centroids), _f32(rows), _f32(Q)
+    nlist = centroids.shape[0]
+    nprobe = min(int(nprobe), nlist)
+    _, probe = search(centroids, Q, nprobe, quantizer_metric)
+    D = np.full((Q.shape[0], k), np.finfo(np.float32).max if metric == METRIC_L2 else -np.finfo(np.float32).max,
+                dtype=np.float32)
+    I = np.full((Q.shape[0], k), -1, dtype=np.int64)
+    for qi in range(Q.shape[0]):
+        sel = np.concatenate([np.arange(offsets[l], offsets[l + 1]) for l in probe[qi] if l >= 0] or [np.zeros(0, int)])
+        if sel.size == 0:
+            continue
+        sel = sel[np.argsort(ids[sel], kind="stable")]        # ascending stored id: the local row number then breaks
+        Dq, Iq = search(rows[sel], Q[qi:qi + 1], k, metric)   # ties exactly as the stored id would
+        ok = Iq[0] >= 0
+        D[qi, ok] = Dq[0, ok]
+        I[qi, ok] = ids[sel][Iq[0, ok]]
+    return D, I
+
+
 def synth_rows(seed: int, row0: int, n: int, d: int) -> np.ndarray:
     """Rows [row0, row0+n) of the deterministic synthetic corpus (see rago_synth_rows)."""
     out = np.empty((n, d), dtype=np.float32)

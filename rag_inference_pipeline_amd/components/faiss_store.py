@@ -47,6 +47,7 @@ class FAISSStore:
         self.index_path = Path(settings.faiss_index_path)
         self._index = None  # rag_inference_pipeline_amd.flat_index.FlatIndex
         self._sharded = None  # rag_inference_pipeline_amd.sharded.ShardedFlatIndex when world > 1
+        self._ivf = None  # rag_inference_pipeline_amd.ivf_index.IVFFlatIndex in the nprobe mode of an IwFl file
         self._ntotal = 0
         self._is_loaded = False
         self._share_stream = 0     # the search stream of a partitioned chip (settings.encoder_cus), made at first use
@@ -84,6 +85,8 @@ class FAISSStore:
             from ..flat_index import SCREEN_FP16, FlatIndex  # raises if librag_amd.so is missing: no fallback
 
             default_metric = index_io.metric_from_name(getattr(self.settings, "faiss_metric", "ip"))
+            if self._load_ivf_nprobe_mode():
+                return
             rows, metric = index_io.read_index_file(
                 self.index_path, default_metric, mmap=bool(getattr(self.settings, "faiss_use_mmap", False)))
             n, d = rows.shape
@@ -129,9 +132,37 @@ class FAISSStore:
             self._is_loaded = False
             raise RuntimeError(f"FAISS index loading failed: {exc}") from exc
 
+    def _load_ivf_nprobe_mode(self) -> bool:
+        """RAG_AMD_IVF_MODE=nprobe on an IndexIVFFlat file, one GPU: keep the inverted lists and search as the reference
+        does with index.nprobe = FAISS_NPROBE (faiss_store.py:84-92).  False: the caller loads the file exhaustively."""
+        mode = str(getattr(self.settings, "faiss_ivf_mode", "exhaustive")).strip().lower()
+        if mode not in ("exhaustive", "nprobe"):
+            raise ValueError(f"RAG_AMD_IVF_MODE must be 'exhaustive' or 'nprobe', got {mode!r}")
+        if mode != "nprobe":
+            return False
+        with open(self.index_path, "rb") as fh:
+            if fh.read(4) != b"IwFl":
+                return False   # not an IVF file: nprobe has no meaning, as for the reference's flat indexes (:84)
+        if self._dist_rank_world()[1] > 1:
+            logger.warning("RAG_AMD_IVF_MODE=nprobe is a one-GPU mode; the sharded deployment searches exhaustively")
+            return False
+        from ..ivf_index import IVFFlatIndex
+
+        lists = index_io.read_ivfflat_lists(self.index_path)
+        nprobe = max(1, int(getattr(self.settings, "faiss_nprobe", 64)))
+        self._ivf = IVFFlatIndex(lists, device=resolve_gpu_device(self.settings), nprobe=nprobe)
+        self._ntotal = lists.ntotal
+        self._is_loaded = True
+        logger.info("Set FAISS nprobe=%d", min(nprobe, lists.nlist))
+        logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (IVFFlat, %d lists)", lists.ntotal,
+                    lists.centroids.shape[1], lists.nlist)
+        if lists.ntotal:
+            self._ivf.search(np.zeros((1, lists.centroids.shape[1]), dtype=np.float32), 1)   # warm-up (:103-107)
+        return True
+
     def search(self, embeddings: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
         """(distances, indices), each (batch, k); reference search(): faiss_store.py:113-158."""
-        if not self._is_loaded or self._index is None:
+        if not self._is_loaded or (self._index is None and self._ivf is None):
             raise RuntimeError("FAISS index not loaded. Call load() first.")
         if embeddings.ndim != 2:
             raise ValueError(f"Embeddings must be 2D array, got shape {embeddings.shape}")
@@ -140,6 +171,10 @@ class FAISSStore:
                 f"Embedding dimension mismatch: expected {self.settings.faiss_dim}, got {embeddings.shape[1]}")
         logger.debug("Searching FAISS index with %d queries, k=%d", embeddings.shape[0], k)
         try:
+            if self._ivf is not None:
+                if isinstance(embeddings, DeviceEmbeddings):
+                    embeddings = embeddings.numpy()
+                return self._ivf.search(np.ascontiguousarray(embeddings, dtype=np.float32), k)
             if isinstance(embeddings, DeviceEmbeddings):
                 # the embedder's result never left HBM: the search is enqueued behind it on its stream and only
                 # ids and scores come back (a sharded deployment ships host bytes in its request message)
@@ -204,6 +239,9 @@ class FAISSStore:
             dev = self._index.device if self._index is not None else 0
             if self._index is not None:
                 self._index.close()
+            if self._ivf is not None:
+                self._ivf.close()
+                self._ivf = None
             if self._share_stream:
                 from ..flat_index import destroy_stream
                 destroy_stream(dev, self._share_stream)
@@ -219,7 +257,7 @@ class FAISSStore:
 
     @property
     def index_size(self) -> int:
-        if not self._is_loaded or self._index is None:
+        if not self._is_loaded or (self._index is None and self._ivf is None):
             return 0
         return int(self._ntotal)
 

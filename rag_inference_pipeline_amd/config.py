@@ -72,6 +72,9 @@ class PipelineSettings(BaseModel):
     # two-stage exact search (include/rag_amd.h rag_index_set_screening): same results as the one-pass
     # fp32 scan at about half the HBM traffic, for +50 % index memory; applies to d <= 2048, k <= 100
     faiss_two_stage: bool = Field(default=True, alias="RAG_AMD_TWO_STAGE")
+    # an IndexIVFFlat file (what the reference's generator writes): "exhaustive" scans every list — more exact than the
+    # reference; "nprobe" restates the reference's search (the FAISS_NPROBE lists nearest to each query: faiss_store.py:84-92)
+    faiss_ivf_mode: str = Field(default="exhaustive", alias="RAG_AMD_IVF_MODE")
     # After the first batch (every component loaded and warm) move what is alive into the collector's permanent
     # generation (gc.freeze): a full collection over a process that has imported torch / transformers / pydantic walks
     # ~10^6 objects and takes 40-60 ms — one batch in ten of a top-100 rerank profile took 65 ms instead of 20.

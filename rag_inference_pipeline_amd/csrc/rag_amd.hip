@@ -1407,6 +1407,8 @@ extern "C" int rag_index_search_gather_device(rag_index* h, rag_comm* c, const f
                                                 out_ids_dev, any_flag_dev, host_mirror, (void*)cst);
 }
 
+#include "rag_ivf_host.hip.h"   // the IVFFlat nprobe mode (rag_ivf_*)
+
 #ifdef RAGK_STAMPS
 // experiment build: phase stamps of the last stamped scan launch, [n_wg][8] (device-synchronising)
 extern "C" int rag_debug_scan_stamps(unsigned long long* out, int32_t n_wg) {

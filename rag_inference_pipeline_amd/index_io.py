@@ -93,22 +93,48 @@ class _Reader:
         return d, ntotal, metric_type
 
 
-def _read_faiss_ivfflat(path: Path) -> tuple[np.ndarray, int]:
+class IVFFlatLists:
+    """What an `IwFl` file holds, as the nprobe mode needs it (rag_ivf_set_lists): the coarse quantizer's centroids
+    and metric, the rows in LIST order with their stored ids, the list boundaries, the metric and the nprobe value
+    saved in the file."""
+
+    def __init__(self, centroids: np.ndarray, quantizer_metric: int, rows: np.ndarray, ids: np.ndarray,
+                 offsets: np.ndarray, metric: int, nprobe: int) -> None:
+        self.centroids, self.quantizer_metric = centroids, quantizer_metric
+        self.rows, self.ids, self.offsets = rows, ids, offsets
+        self.metric, self.nprobe = metric, nprobe
+
+    @property
+    def nlist(self) -> int:
+        return int(self.centroids.shape[0])
+
+    @property
+    def ntotal(self) -> int:
+        return int(self.rows.shape[0])
+
+
+def read_ivfflat_lists(path: str | os.PathLike) -> IVFFlatLists:
+    """Parse a FAISS IndexIVFFlat file (fourcc `IwFl`) without flattening it.  Layout restated from upstream
+    (faiss/impl/index_write.cpp), validated structurally and through this module's own writer (faiss is absent)."""
+    path = Path(path)
     r = _Reader(path)
     if r.array(np.uint8, 4).tobytes() != b"IwFl":
         raise ValueError(f"{path}: not an IwFl file")
     d, ntotal, metric_type = r.index_header()
     if metric_type > 1 or d <= 0 or ntotal < 0:
         raise ValueError(f"{path}: unsupported IVF header (d={d}, ntotal={ntotal}, metric_type={metric_type})")
-    nlist, _nprobe = r.take("QQ")
-    # coarse quantizer: a nested flat index holding nlist centroids — skipped
+    nlist, nprobe = r.take("QQ")
+    # coarse quantizer: a nested flat index holding nlist centroids
     qcc = r.array(np.uint8, 4).tobytes()
     if qcc not in _FLAT_FOURCC:
         raise ValueError(f"{path}: coarse quantizer {qcc!r} is not a flat index")
-    qd, qn, _ = r.index_header()
-    r.array(np.float32, r.take("Q"))
-    if qd != d or qn != nlist:
+    qd, qn, q_metric_type = r.index_header()
+    centroids = np.array(r.array(np.float32, r.take("Q")))
+    if qd != d or qn != nlist or centroids.size != nlist * d:
         raise ValueError(f"{path}: quantizer shape ({qn}, {qd}) does not match nlist={nlist}, d={d}")
+    q_metric = _FLAT_FOURCC[qcc]
+    if q_metric is None:
+        q_metric = METRIC_INNER_PRODUCT if q_metric_type == 0 else METRIC_L2
     # direct map: type byte, array, and (hashtable type only) a vector of (id, offset) pairs
     dm_type = r.take("B")
     r.array(np.int64, r.take("Q"))
@@ -138,39 +164,59 @@ def _read_faiss_ivfflat(path: Path) -> tuple[np.ndarray, int]:
         raise ValueError(f"{path}: unknown list encoding {list_type!r}")
     if int(sizes.sum()) != ntotal:
         raise ValueError(f"{path}: inverted lists hold {int(sizes.sum())} vectors, header says {ntotal}")
+    offsets = np.zeros(nlist + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offsets[1:])
     rows = np.empty((ntotal, d), dtype=np.float32)
-    seen = np.zeros(ntotal, dtype=bool)
-    for n in sizes:
-        n = int(n)
+    ids = np.empty(ntotal, dtype=np.int64)
+    for l in range(nlist):
+        n = int(sizes[l])
         if n == 0:
             continue
-        codes = r.array(np.float32, n * d).reshape(n, d)
-        ids = r.array(np.int64, n)
-        if ids.min() < 0 or ids.max() >= ntotal or seen[ids].any():
-            raise ValueError(f"{path}: stored ids are not a permutation of 0..ntotal-1; row order cannot be restored")
-        seen[ids] = True
-        rows[ids] = codes
-    if not seen.all():
-        raise ValueError(f"{path}: some ids are missing from the inverted lists")
-    return rows, (METRIC_INNER_PRODUCT if metric_type == 0 else METRIC_L2)
+        lo = int(offsets[l])
+        rows[lo:lo + n] = r.array(np.float32, n * d).reshape(n, d)
+        ids[lo:lo + n] = r.array(np.int64, n)
+    return IVFFlatLists(centroids.reshape(nlist, d), q_metric, rows, ids, offsets,
+                        METRIC_INNER_PRODUCT if metric_type == 0 else METRIC_L2, int(nprobe))
+
+
+def _read_faiss_ivfflat(path: Path) -> tuple[np.ndarray, int]:
+    """The exhaustive view of an IwFl file: rows back in stored-id order (the nprobe = nlist limit)."""
+    lists = read_ivfflat_lists(path)
+    ntotal = lists.ntotal
+    ids = lists.ids
+    if ntotal and (ids.min() < 0 or ids.max() >= ntotal or np.unique(ids).size != ntotal):
+        raise ValueError(f"{path}: stored ids are not a permutation of 0..ntotal-1; row order cannot be restored")
+    rows = np.empty_like(lists.rows)
+    rows[ids] = lists.rows
+    return rows, lists.metric
 
 
 def write_ivfflat_index(path: str | os.PathLike, rows: np.ndarray, nlist: int, metric: int = METRIC_L2,
-                        seed: int = 0, sparse: bool = False) -> None:
+                        seed: int = 0, sparse: bool = False, nprobe: int = 1, all_centroids: bool = False) -> None:
     """Write rows as a FAISS-layout IndexIVFFlat file (test helper: random centroids taken from the rows,
-    nearest-centroid assignment).  Mirrors what scripts/create_test_docs.py produces with faiss itself."""
+    nearest-centroid assignment — over the first 64 centroids, or over all of them with `all_centroids`).  Mirrors
+    what scripts/create_test_docs.py produces with faiss itself."""
     rows = np.ascontiguousarray(rows, dtype=np.float32)
     n, d = rows.shape
     rng = np.random.default_rng(seed)
     cent = rows[rng.choice(n, size=min(nlist, n), replace=False)] if n else np.zeros((0, d), np.float32)
     if cent.shape[0] < nlist:
         cent = np.concatenate([cent, np.zeros((nlist - cent.shape[0], d), np.float32)])
-    assign = np.argmin(((rows[:, None, :] - cent[None, :min(nlist, 64), :]) ** 2).sum(-1), axis=1) if n else np.zeros(0, int)
+    if not n:
+        assign = np.zeros(0, int)
+    elif all_centroids:
+        cn = (cent.astype(np.float64) ** 2).sum(1)
+        assign = np.empty(n, dtype=np.int64)
+        for lo in range(0, n, 8192):
+            blk = rows[lo:lo + 8192].astype(np.float64)
+            assign[lo:lo + 8192] = np.argmin(cn[None, :] - 2.0 * blk @ cent.astype(np.float64).T, axis=1)
+    else:
+        assign = np.argmin(((rows[:, None, :] - cent[None, :min(nlist, 64), :]) ** 2).sum(-1), axis=1)
     metric_type = 0 if metric == METRIC_INNER_PRODUCT else 1
     with open(path, "wb") as fh:
         fh.write(b"IwFl")
         fh.write(_HEADER.pack(d, n, 1 << 20, 1 << 20, 1, metric_type))
-        fh.write(struct.pack("<QQ", nlist, 1))
+        fh.write(struct.pack("<QQ", nlist, nprobe))
         fh.write(b"IxF2")
         fh.write(_HEADER.pack(d, nlist, 1 << 20, 1 << 20, 1, 1))
         fh.write(struct.pack("<Q", nlist * d))
@@ -178,7 +224,10 @@ def write_ivfflat_index(path: str | os.PathLike, rows: np.ndarray, nlist: int, m
         fh.write(struct.pack("<BQ", 0, 0))  # no direct map
         fh.write(b"ilar")
         fh.write(struct.pack("<QQ", nlist, 4 * d))
-        members = [np.nonzero(assign == l)[0].astype(np.int64) for l in range(nlist)]
+        order = np.argsort(assign, kind="stable")
+        counts = np.bincount(assign, minlength=nlist) if n else np.zeros(nlist, dtype=np.int64)
+        bounds = np.concatenate([[0], np.cumsum(counts)])
+        members = [order[bounds[l]:bounds[l + 1]].astype(np.int64) for l in range(nlist)]
         if sparse:
             pairs = [(l, len(m)) for l, m in enumerate(members) if len(m)]
             fh.write(b"sprs")

@@ -1,0 +1,135 @@
+"""IVFFlat `nprobe` mode: the oracle's restatement (CPU) and the HIP path against it (gpu).
+
+The reference's own generator writes a faiss IndexIVFFlat (scripts/create_test_docs.py:83-104) and FAISSStore.load sets
+index.nprobe (faiss_store.py:84-92): on that file the reference looks only at the nprobe lists nearest to a query.
+faiss is absent here, so parity is unpinned as for the flat search; what is held: oracle == a literal float64 numpy
+restatement of "nearest lists, then exact top-k of their rows"; HIP == oracle (ids and fp32 score bits); nprobe = nlist
+== the exhaustive flat search."""
+import numpy as np
+import pytest
+
+from oracle import flat as oracle
+from rag_inference_pipeline_amd import index_io
+
+
+def _unit(rng, n, d):
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _file(tmp_path, n, d, nlist, metric, seed=0, sparse=False, nprobe=7):
+    rng = np.random.default_rng(seed)
+    X = _unit(rng, n, d)
+    path = tmp_path / f"ivf_{n}_{d}_{nlist}_{metric}.index"
+    index_io.write_ivfflat_index(path, X, nlist, metric, seed=seed, sparse=sparse, nprobe=nprobe, all_centroids=True)
+    return X, path
+
+
+def test_lists_roundtrip_and_exhaustive_view(tmp_path):
+    X, path = _file(tmp_path, 3000, 24, 50, 1, sparse=True, nprobe=9)
+    lists = index_io.read_ivfflat_lists(path)
+    assert (lists.nlist, lists.ntotal, lists.nprobe, lists.metric, lists.quantizer_metric) == (50, 3000, 9, 1, 1)
+    assert lists.offsets[0] == 0 and lists.offsets[-1] == 3000 and (np.diff(lists.offsets) >= 0).all()
+    np.testing.assert_array_equal(np.sort(lists.ids), np.arange(3000))
+    np.testing.assert_array_equal(lists.rows, X[lists.ids])                 # list order, stored ids alongside
+    for l in (0, 17, 49):                                                   # members of a list are nearest to ITS centroid
+        rows = lists.rows[lists.offsets[l]:lists.offsets[l + 1]]
+        if len(rows):
+            d2 = ((rows[:, None, :].astype(np.float64) - lists.centroids[None].astype(np.float64)) ** 2).sum(-1)
+            assert (np.argmin(d2, axis=1) == l).all()
+    rows, metric = index_io.read_index_file(path)
+    np.testing.assert_array_equal(rows, X)
+    assert metric == 1
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_oracle_is_nearest_lists_then_exact_topk(tmp_path, metric):
+    X, path = _file(tmp_path, 4000, 32, 64, metric, seed=3)
+    lists = index_io.read_ivfflat_lists(path)
+    Q = _unit(np.random.default_rng(5), 9, 32)
+    k, nprobe = 10, 5
+    D, I = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, metric)
+    X64, Q64, C64 = X.astype(np.float64), Q.astype(np.float64), lists.centroids.astype(np.float64)
+    assign = np.empty(4000, dtype=np.int64)
+    for l in range(64):
+        assign[lists.ids[lists.offsets[l]:lists.offsets[l + 1]]] = l
+    for qi in range(9):
+        near = np.argsort(((C64 - Q64[qi]) ** 2).sum(1), kind="stable")[:nprobe]      # the quantizer is L2
+        cand = np.nonzero(np.isin(assign, near))[0]
+        score = X64[cand] @ Q64[qi] if metric == 0 else -((X64[cand] - Q64[qi]) ** 2).sum(1)
+        want = cand[np.argsort(-score, kind="stable")[:k]]
+        np.testing.assert_array_equal(I[qi], want)
+        assert set(np.unique(assign[I[qi]])) <= set(near.tolist())
+    # every list probed: the exhaustive flat search
+    Df, If = oracle.search(X, Q, k, metric)
+    Da, Ia = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, 64, metric)
+    np.testing.assert_array_equal(Ia, If)
+    np.testing.assert_array_equal(Da.view(np.uint32), Df.view(np.uint32))
+
+
+def test_settings_carry_the_ivf_mode(monkeypatch):
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    assert PipelineSettings().faiss_ivf_mode == "exhaustive"
+    assert PipelineSettings(RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=12).faiss_nprobe == 12
+
+
+# ---- gpu ----------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,nlist,metric,nq,k", [
+    (60_000, 64, 4096, 1, 32, 10),      # the generator's shape of index (L2, nlist 4096), scaled down
+    (60_000, 64, 4096, 0, 32, 100),
+    (20_000, 384, 256, 1, 9, 10),
+    (5_000, 100, 300, 0, 3, 256),       # d not a multiple of 8, lists of a dozen rows, the largest k
+    (700, 32, 1000, 1, 5, 10),          # more lists than rows: most lists are empty
+])
+def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlist, metric, nq, k):
+    from rag_inference_pipeline_amd.flat_index import FlatIndex
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    X, path = _file(tmp_path, n, d, nlist, metric, seed=n + d)
+    lists = index_io.read_ivfflat_lists(path)
+    Q = _unit(np.random.default_rng(11), nq, d)
+    Q[0] = X[123 % n]                                           # a query that is a corpus row
+    idx = IVFFlatIndex(lists, nprobe=8)
+    assert (idx.ntotal, idx.nlist, idx.nprobe) == (n, nlist, 8)
+    for nprobe in (1, 8, 64):
+        D, I = idx.search(Q, k, nprobe=nprobe)
+        Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, metric)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    if nlist <= 2048:   # every list probed == the exhaustive search, bit for bit
+        flat = FlatIndex(d, metric)
+        flat.add(X)
+        Df, If = flat.search(Q, k)
+        Da, Ia = idx.search(Q, k, nprobe=nlist)
+        np.testing.assert_array_equal(Ia, If)
+        np.testing.assert_array_equal(Da.view(np.uint32), Df.view(np.uint32))
+        flat.close()
+    with pytest.raises(Exception, match="256"):
+        idx.search(Q, 300)
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_faiss_store_nprobe_mode_end_to_end(gpu_required, tmp_path):
+    from rag_inference_pipeline_amd.components.faiss_store import FAISSStore
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    n, d, nlist = 30_000, 96, 512
+    X, path = _file(tmp_path, n, d, nlist, 1, seed=2, nprobe=64)
+    lists = index_io.read_ivfflat_lists(path)
+    Q = _unit(np.random.default_rng(4), 32, d)
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), FAISS_DIM=d, RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=4))
+    store.load()
+    assert store.is_loaded and store.index_size == n
+    D, I = store.search(Q, 10)
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, 10, 4, 1)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    store.unload()
+    exhaustive = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), FAISS_DIM=d))   # the default: every list
+    exhaustive.load()
+    De, Ie = exhaustive.search(Q, 10)
+    Df, If = oracle.search(X, Q, 10, 1)
+    np.testing.assert_array_equal(Ie, If)
+    assert (I != Ie).any()          # nprobe = 4 of 512 lists misses true neighbours: the two modes differ, as documented
+    exhaustive.unload()
