@@ -118,7 +118,7 @@ def test_faiss_store_nprobe_mode_end_to_end(gpu_required, tmp_path):
     X, path = _file(tmp_path, n, d, nlist, 1, seed=2, nprobe=64)
     lists = index_io.read_ivfflat_lists(path)
     Q = _unit(np.random.default_rng(4), 32, d)
-    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), FAISS_DIM=d, RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=4))
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), faiss_dim=d, RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=4))
     store.load()
     assert store.is_loaded and store.index_size == n
     D, I = store.search(Q, 10)
@@ -126,7 +126,7 @@ def test_faiss_store_nprobe_mode_end_to_end(gpu_required, tmp_path):
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
     store.unload()
-    exhaustive = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), FAISS_DIM=d))   # the default: every list
+    exhaustive = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), faiss_dim=d))   # the default: every list
     exhaustive.load()
     De, Ie = exhaustive.search(Q, 10)
     Df, If = oracle.search(X, Q, 10, 1)
