@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
-TRAFFIC_FILE = "r03_scan_hbm_traffic.json"  # PMC pass of this workload (profiles/README.md says how it was collected)
+TRAFFIC_FILE = "r04_scan_hbm_traffic.json"  # PMC pass of this workload (profiles/README.md says how it was collected)
 
 # xor of the returned ids for the default workload (rows, dim, batch, k, seed), as produced by the
 # 1-GPU run that the full-size parity test checks against the oracle; sharded runs must reproduce it
@@ -144,6 +144,59 @@ def cpu_baseline(args: argparse.Namespace) -> dict:
                     "sample": f"faiss {faiss.__version__} IndexFlatIP.search, {cores} OpenMP threads, on the first {n} of "
                               f"{args.rows} rows, {r3} batches at {e3 / r3 * 1e3:.1f} ms/batch; scaled x{scale:g}",
                     "port": port, "faiss": faiss.__version__})
+    return out
+
+
+# ---- MFMA rooflines of the transformer legs ------------------------------------------------------------------------------
+# achieved TF/s is computed live (GEMM + attention flops the pass executes / measured time); the matrix-pipe busy
+# fraction and the HBM floor come from counter passes of the same workload (separate rocprofv3 --pmc runs, as the guide
+# prescribes) committed under profiles/ — the `*_source` fields name the file, nothing is collected inside this run.
+FP32_MFMA_PEAK_TF = 157.3            # dense v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TF = 2500.0            # dense fp16 / bf16 (the 5 PF headline figure includes 2:1 sparsity)
+
+
+def _profile_json(name: str):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def transformer_flops(hidden: int, inter: int, layers: int, lens, head: bool, first_only: bool) -> float:
+    """GEMM + attention flops a forward pass over sequences of `lens` tokens executes (rag_bert.hip: with an output
+    that reads first tokens only, the last layer's projections after attention run on one row per sequence)."""
+    T, nseq = float(sum(int(x) for x in lens)), float(len(lens))
+    per_token = 2.0 * (3 * hidden * hidden + hidden * hidden + 2 * hidden * inter)
+    total = per_token * layers * T + (2.0 * hidden * hidden * nseq if head else 0.0)
+    if first_only and nseq < T:
+        total -= 2.0 * (hidden * hidden + 2 * hidden * inter) * (T - nseq)
+    return total + sum(4.0 * int(L) * int(L) * hidden for L in lens) * layers
+
+
+def mfma_roofline(flops: float, ms: float, peak_tf: float, basis: str, kernel: str, busy_file: str | None, busy_key=None,
+                  floor_file: str | None = None) -> dict:
+    achieved = flops / (ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": peak_tf, "unit": "TFLOP/s",
+           "frac": achieved / peak_tf, "peak_basis": basis, "flops_per_pass": flops}
+    prof = _profile_json(busy_file) if busy_file else None
+    busy = None
+    if prof is not None:
+        try:
+            busy = busy_key(prof) if busy_key else prof["derived"]["mfma_utilisation"]
+        except (KeyError, TypeError, IndexError):
+            busy = None
+    out["mfma_busy"] = busy
+    out["mfma_busy_source"] = (f"profiles/{busy_file}: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x GRBM_GUI_ACTIVE) from a separate "
+                               "rocprofv3 --pmc pass of this workload; not collected inside this run") if busy is not None else None
+    fl = _profile_json(floor_file) if floor_file else None
+    try:
+        out["hbm_floor_ms"] = fl["per_pass"]["hbm_floor_ms_at_6.3TBps"] if fl else None
+    except (KeyError, TypeError):
+        out["hbm_floor_ms"] = None
+    out["hbm_floor_source"] = (f"profiles/{floor_file}: (FETCH_SIZE x 2 + WRITE_SIZE) of one pass / 6.3 TB/s (the guide's "
+                               "achievable HBM rate)") if out["hbm_floor_ms"] is not None else None
     return out
 
 
@@ -411,6 +464,25 @@ def main() -> None:
                 return el
 
             el = timed_loop(enc_step)
+            # the encoder by itself (HIP events on its stream), for its own roofline object
+            for _ in range(3):
+                model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                     _native.BERT_OUT_CLS, True, Qe2[0].data_ptr(), sptr)
+            torch.cuda.synchronize()
+            ee0, ee1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ee0.record()
+            for _ in range(20):
+                model.forward_device(ids_t.data_ptr(), 0, cu_t.data_ptr(), B, int(cu_np[-1]), int(lens.max()),
+                                     _native.BERT_OUT_CLS, True, Qe2[0].data_ptr(), sptr)
+            ee1.record()
+            torch.cuda.synchronize()
+            enc_only_ms = ee0.elapsed_time(ee1) / 20
+            enc_roof = mfma_roofline(transformer_flops(ecfg.hidden, ecfg.intermediate, ecfg.n_layers, lens, head=False, first_only=True),
+                                     enc_only_ms, F16_MFMA_PEAK_TF / 3.0,
+                                     "fp16 MFMA, three products per fp32-accurate product: 2.5 PF/s / 3 (a 447-token batch is "
+                                     "launch- and operand-latency-bound, not matrix-bound: DESIGN.md section 4)",
+                                     "gemm_nt_ws_kernel<1|2,4> (64-row tiles, split-K)", "r04_encoder_mfma_util.json")
+            enc_roof["encoder_alone_ms"] = enc_only_ms
             model.set_background(True)    # kernels that fit beside the scan's resident workgroups (include/rag_amd.h)
             el_p = timed_loop(enc_pipe_step)
             model.set_background(False)
@@ -483,6 +555,7 @@ def main() -> None:
                 pipelined = run_partitioned(int(os.environ.get("RAG_AMD_BENCH_ENCODER_CUS", "32")), pipelined)
             enc_leg = {"value": B * args.steps / el, "unit": "queries/s", "ms_per_step": el / args.steps * 1e3,
                        "tokens_per_batch": int(cu_np[-1]),
+                       "roofline": enc_roof,
                        "pipelined": pipelined,
                        "encoder": "bge-base-en-v1.5 architecture (12x768), seeded random weights, CLS pooling + L2 norm, "
                                   "two-plane fp16 GEMMs (fp32 accuracy); token ids resident in HBM"}
@@ -528,8 +601,20 @@ def main() -> None:
                 e1.record()
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 5
+                rflops = transformer_flops(rcfg.hidden, rcfg.intermediate, rcfg.n_layers, plens, head=True, first_only=True)
+                if mode == "f32":
+                    roof = mfma_roofline(rflops, ms, F16_MFMA_PEAK_TF / 3.0,
+                                         "fp16 MFMA, three products per fp32-accurate product: 2.5 PF/s / 3",
+                                         "gemm_nt_wl_kernel<2,1,3> (78 % of the pass)", "r04_rerank_gemm_mfma_util.json")
+                else:
+                    roof = mfma_roofline(rflops, ms, F16_MFMA_PEAK_TF, "fp16 MFMA dense, 2.5 PF/s",
+                                         "gemm_nt_wt_kernel<1,8,4,...> (fp16 activations in fragment order)",
+                                         "r04_rerank_f16_minilm_pass.json",
+                                         busy_key=lambda pr: max((kk.get("mfma_busy_frac") or 0.0) for kk in pr["kernels"]
+                                                                 if "gemm_nt_wt" in kk["kernel"]),
+                                         floor_file="r04_rerank_f16_minilm_pass.json")
                 rerank_leg[key] = {"ms_per_batch": ms, "pairs_per_s": len(pseqs) / ms * 1e3,
-                                   "score_checksum": float(pout.sum().item())}
+                                   "score_checksum": float(pout.sum().item()), "roofline": roof}
                 rmodel.close()
             rerank_leg["note"] = ("default: GEMMs on the fp16 matrix cores with every fp32 operand as two fp16 planes (fp32 accuracy); "
                                   "fp16_mode (RAG_AMD_RERANKER_DTYPE=f16): fp16 activations stored in MFMA-fragment order, GEMMs and "

@@ -1156,3 +1156,4 @@ __global__ __launch_bounds__(64) void head_out_kernel(const float* x, const floa
 #include "bert_lnf.hip.h"  // small kernels of the query encoder's folded LayerNorms
 #include "gemm_wt.hip.h"  // the same over activations in MFMA-fragment order (RAG_GEMM_F16 big-batch path)
 #include "bert_tiled.hip.h"  // embedding, LayerNorm, attention, pooling over that layout
+#include "ffn_fused_t16.hip.h"  // the feed-forward block as one kernel on that layout (hidden 384)

@@ -52,6 +52,7 @@ struct rag_bert {
     std::vector<_Float16*> wx2;
     std::vector<__bf16*> wx;
     std::vector<_Float16*> wxf;
+    std::vector<_Float16*> wffn2p;    // RAG_GEMM_F16, hidden 384: W2 of every layer in accumulator column order (ffn_fused_t16.hip.h)
     // LayerNorm folded into its consumers (gemm_wl.hip.h; query-encoder path, <= 1024 tokens): per layer the two-plane
     // images of the QKV and feed-forward input weights with the preceding LayerNorm's gamma folded in, and for each the
     // vectors s[n] = sum_k W'[n][k] and bias2 = bias + W beta.  Built at create when the model qualifies (lnf_ok).
@@ -241,6 +242,21 @@ int launch_gemm_t16(const _Float16* A, int lda, const _Float16* Wimg, const floa
     const ragb::GemmWtParams g{A, Wimg, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
     if (K >= 1536 && K % 32 == 0) return launch_wt<1, 8, 4, 2, 3, 2>(g, st);
     return launch_wt<1, 8, 4, 1, 4, 3>(g, st);
+}
+
+// The feed-forward block of a layer as one kernel (ffn_fused_t16.hip.h): hidden 384, GELU (erf), I % 128 == 0.
+int launch_ffn_fused_t16(const _Float16* X, const _Float16* W1img, const float* b1, const _Float16* W2pimg, const float* b2,
+                         _Float16* Y, int M, int I, hipStream_t st) {
+    using Geo = ragb::FfnFusedGeom<12>;
+    auto fn = &ragb::ffn_fused_t16_kernel<12>;
+    const int lds = Geo::lds(I);
+    int rc = ensure_lds(reinterpret_cast<const void*>(fn), lds);
+    if (rc) return rc;
+    const ragb::FfnFusedParams g{X, W1img, b1, W2pimg, b2, Y, M, I};
+    const int nrb = (M + 31) / 32;
+    hipLaunchKernelGGL(fn, dim3((unsigned)((nrb + 3) / 4)), dim3(256), lds, st, g);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
 }
 
 // Small batches on the two-plane path: 64 x 64 tiles while they fit the chip in one round, 64 x 128 beyond that.
@@ -635,10 +651,16 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             if (rc) return rc;
             ln_tiled(parth, lw[4], lw[5], xh);
             RAGC_HIP_TRY(hipGetLastError());
-            rc = launch_gemm_t16(xh, H, h->wxf[at + 2], lw[7], nullptr, 0, ffnh, I, T, I, H, act, st);
-            if (rc) return rc;
-            rc = launch_gemm_t16(ffnh, I, h->wxf[at + 3], lw[9], xh, H, parth, H, T, H, I, ACT_NONE, st);
-            if (rc) return rc;
+            if (!h->wffn2p.empty() && h->wffn2p[l]) {
+                // FFN-in -> GELU -> FFN-out + residual in one kernel: the 4 x wider intermediate never reaches HBM
+                rc = launch_ffn_fused_t16(xh, h->wxf[at + 2], lw[7], h->wffn2p[l], lw[9], parth, T, I, st);
+                if (rc) return rc;
+            } else {
+                rc = launch_gemm_t16(xh, H, h->wxf[at + 2], lw[7], nullptr, 0, ffnh, I, T, I, H, act, st);
+                if (rc) return rc;
+                rc = launch_gemm_t16(ffnh, I, h->wxf[at + 3], lw[9], xh, H, parth, H, T, H, I, ACT_NONE, st);
+                if (rc) return rc;
+            }
             ln_tiled(parth, lw[10], lw[11], xh);
             RAGC_HIP_TRY(hipGetLastError());
             continue;
@@ -1072,6 +1094,33 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
             }
         }
     }
+    if (c.gemm_mode == RAG_GEMM_F16 && c.hidden == 384 && c.intermediate % 128 == 0 && c.act == RAG_ACT_GELU) {
+        // Built, exact, and NOT faster (round 4: 7.54 ms per 3200-pair pass against 7.46 with the two GEMMs): with one wave
+        // per SIMD — the price of keeping a 32 x 384 fp32 tile and the X fragments in registers — nothing overlaps the
+        // GELU's vector work or the weight stream (ablations: the skeleton alone, no DMA / MFMA / LDS reads, takes 0.49 of
+        // the 0.73 ms per layer).  It does take the intermediate's 6.6 GB per pass off HBM.  Opt-in.
+        const char* ff = getenv("RAG_AMD_FFN_FUSED");
+        if (ff && *ff == '1') {
+            h->wffn2p.assign((size_t)c.n_layers, nullptr);
+            const int H = c.hidden, I = c.intermediate;
+            for (int l = 0; l < c.n_layers && rc == RAG_OK; ++l) {
+                void* img = nullptr;
+                if (hipMalloc(&img, (size_t)H * I * sizeof(_Float16)) != hipSuccess) {
+                    rc = ragc_fail(RAG_ERR_OOM, "device allocation of the fused feed-forward weight image failed");
+                    break;
+                }
+                h->wffn2p[(size_t)l] = static_cast<_Float16*>(img);
+                const float* W2 = h->w[kEmbEntries + kPerLayer * l + 8];
+                ragb::pack_f16_accorder_kernel<<<dim3((unsigned)(((long long)H * I + 255) / 256)), dim3(256), 0, h->stream>>>(W2, H, I, I, h->wffn2p[(size_t)l]);
+            }
+            if (rc == RAG_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess))
+                rc = ragc_fail(RAG_ERR_HIP, "building the fused feed-forward weight images failed");
+            if (rc) {
+                rag_bert_destroy(h);
+                return rc;
+            }
+        }
+    }
     if (c.gemm_mode == RAG_GEMM_F32 && h->weights_fit_f16) {
         // Measured slower and therefore OFF unless asked for (RAG_AMD_ENCODER_LN_FOLD=1): handing a tile's slabs from one
         // workgroup to another inside a launch costs two to three memory-side round trips (agent-scope stores, the arrival
@@ -1104,6 +1153,8 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
         for (_Float16* p : h->wxf)
             if (p) (void)hipFree(p);
         for (_Float16* p : h->wfold)
+            if (p) (void)hipFree(p);
+        for (_Float16* p : h->wffn2p)
             if (p) (void)hipFree(p);
         for (float* p : h->fold_s)
             if (p) (void)hipFree(p);

@@ -419,6 +419,34 @@ def test_layernorms_folded_into_their_consumers_match_the_separate_launches(gpu_
     plain.close()
 
 
+def test_fused_feed_forward_kernel_matches_the_two_gemms(gpu_required, monkeypatch):
+    """RAG_AMD_FFN_FUSED=1 (fp16 mode, hidden 384): FFN-in -> GELU -> FFN-out + residual as one kernel whose 1536-wide
+    intermediate stays in registers (the H1 tile's accumulator registers are the second product's operand; W2's image is
+    packed in that column order).  Same values as the two-GEMM form to fp16 rounding — the intermediate is rounded to
+    fp16 at the same point in both, only the fp32 accumulation order differs — and inside the fp16 mode's bound against
+    the oracle; ragged token counts (partial row blocks) included."""
+    cfg = _small(BertConfig.ms_marco_minilm_l6())
+    cfg.gemm_dtype = "f16"
+    w = random_weights(cfg, 55)
+    w["head_out_w"] = (w["head_out_w"] * 20).astype(np.float32)
+    monkeypatch.setenv("RAG_AMD_FFN_FUSED", "1")
+    fused = BertModel(cfg, w)
+    monkeypatch.delenv("RAG_AMD_FFN_FUSED")
+    plain = BertModel(cfg, w)
+    rng = np.random.default_rng(55)
+    for n_pairs in (40, 97):   # ~1800 and ~4400 tokens, neither a multiple of 32 or 128
+        seqs = _seqs(rng, rng.integers(24, 65, size=n_pairs), cfg.vocab_size)
+        types = [[0] * 10 + [1] * (len(q) - 10) for q in seqs]
+        a, b = fused.classify(seqs, types, sigmoid=False), plain.classify(seqs, types, sigmoid=False)
+        want = obert.classify(cfg, w, seqs, types, sigmoid=False)
+        assert np.abs(a - b).max() < 0.02, np.abs(a - b).max()
+        assert np.abs(a - want).max() < 0.08 and np.abs(b - want).max() < 0.08
+        ha, hb = fused.hidden_states(seqs, types), plain.hidden_states(seqs, types)
+        np.testing.assert_allclose(ha, hb, atol=2e-2, rtol=2e-2)
+    fused.close()
+    plain.close()
+
+
 def test_cached_encoder_graphs_survive_a_workspace_reallocation(gpu_required, monkeypatch):
     """A cached graph holds the activation workspace's addresses.  A later pass that needs a bigger workspace — an eager
     embed() of more tokens than the graph path ever takes — frees and reallocates those buffers; the next replay of the
