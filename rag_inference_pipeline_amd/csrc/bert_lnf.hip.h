@@ -58,12 +58,12 @@ __global__ __launch_bounds__(256) void embed_pre_kernel(const EmbedParams p, flo
 // x[t] = LayerNorm(y[t]) from the block statistics: the one place a folded LayerNorm is materialised (the end of the
 // encoder, in front of pooling / the hidden-state output).  One wave per token.
 __global__ __launch_bounds__(256) void ln_from_tiles_kernel(const float* y, const float2* ts, const float* g, const float* b,
-                                                           float* x, int T, int H, float eps) {
+                                                           float* x, int T, int H, float eps, int blkw) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
     float mean, rstd;
-    lnf_row_stats(ts + (size_t)t * (H >> 5), H >> 5, eps, mean, rstd);
+    lnf_row_stats(ts + (size_t)t * (H / blkw), H / blkw, eps, mean, rstd, (float)blkw);
     const int nch = H >> 2;
     for (int ch = lane; ch < nch; ch += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)t * H + 4 * ch);
@@ -78,13 +78,13 @@ __global__ __launch_bounds__(256) void ln_from_tiles_kernel(const float* y, cons
 
 // out[s] = LayerNorm(y[first token of sequence s]) — the residual rows of a last layer that runs on first tokens only
 __global__ __launch_bounds__(256) void gather_rows_ln_kernel(const float* y, const float2* ts, const float* g, const float* b,
-                                                            const int* cu, float* out, int nseq, int H, float eps) {
+                                                            const int* cu, float* out, int nseq, int H, float eps, int blkw) {
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= nseq) return;
     const int t = cu[s];
     float mean, rstd;
-    lnf_row_stats(ts + (size_t)t * (H >> 5), H >> 5, eps, mean, rstd);
+    lnf_row_stats(ts + (size_t)t * (H / blkw), H / blkw, eps, mean, rstd, (float)blkw);
     const int nch = H >> 2;
     for (int ch = lane; ch < nch; ch += 64) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)t * H + 4 * ch);
@@ -95,6 +95,16 @@ __global__ __launch_bounds__(256) void gather_rows_ln_kernel(const float* y, con
         for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
         *reinterpret_cast<f32x4*>(out + (size_t)s * H + 4 * ch) = o;
     }
+}
+
+// rs[t] = (mean, rstd) of row t from its tile statistics: one thread per row, one pass — so that the big-batch consumers
+// read ONE value per row (by DMA) instead of combining the tiles themselves in front of their epilogue.
+__global__ void lnf_finalize_kernel(const float2* ts, int nblk, float blkw, float eps, float2* rs, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float mean, rstd;
+    lnf_row_stats(ts + (size_t)t * nblk, nblk, eps, mean, rstd, blkw);
+    rs[t] = make_float2(mean, rstd);
 }
 
 // For a GEMM C = LN(y) W^T + bias with the LayerNorm folded (W' = W gamma in its image):

@@ -52,6 +52,16 @@ struct GemmWlParams {
     int lda, ldr, ldc;
     int act;
     uint32_t* range_flag;  // MODE 2: set to 1 when an element of A is outside fp16's range (|x| >= 65504); may be null
+    // ---- LayerNorm folded into its consumers, big-batch form (wl_epilogue_lnf; all null / 0 = the plain epilogue).  Block
+    // statistics here are per (row, 128-column tile).
+    const float2* rs_in;   // [M] (mean, rstd) of the rows whose LayerNorm is pending (A's rows for form A, Ry's for B), finished
+                           // by lnf_finalize_kernel from the producer's tile statistics; the kernel DMAs its 128 rows' worth
+                           // into LDS with its first stage, so no load sits in front of the epilogue
+    const float* fold_s;   // form A: s[n] = sum_k W'[n][k]; C = act(rstd (acc - mean s[n]) + bias[n]), bias = b + W beta
+    const float* Ry;       // form B: residual BEFORE its LayerNorm [M][ldr]: R = (Ry - mean) rstd ln_g[n] + ln_b[n]
+    const float* ln_g;
+    const float* ln_b;
+    float2* ts_out;        // form B: [M][N / 128] statistics of the rows written (C = acc + bias + R, no LayerNorm applied)
 };
 
 // W fp32 [N][K] -> fp16 image in MFMA-fragment order: fragment (nt, ks) holds, for lane (r, h), the eight values
@@ -111,9 +121,52 @@ struct WlGeom {
     static constexpr int STAGE = A_STAGE + W_STAGE;
     static constexpr int RING = NS * STAGE;
     static constexpr int EPI = 4 * 16 * 132 * 4;              // epilogue: per wave 16 rows x 132 floats
-    static constexpr int LDS = RING > EPI ? RING : EPI;
+    static constexpr int ROWST = RING > EPI ? RING : EPI;     // behind both: 4 waves x 32 rows x (mean, rstd), DMA-filled
+    static constexpr int LDS = ROWST + 4 * 32 * 8;
     static constexpr int G = 2 * KS + KS * PL;                // LDS-DMA instructions per wave per stage
 };
+
+// ---- block statistics of rows whose LayerNorm is applied by their consumers ("LayerNorm folded into its consumers", below)
+// `blkw` = columns per block: 32 on the query-encoder path (a wave's 32 x 32 accumulator tile), 128 on the big-batch path
+// (a row of a 128 x 128 workgroup tile).
+__device__ __forceinline__ void lnf_row_stats(const float2* ts, int nblk, float eps, float& mean, float& rstd, float blkw = 32.f) {
+    float sm = 0.f, sM2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float2 q = ts[b];
+        sm += q.x;
+        sM2 += q.y;
+    }
+    mean = sm / (float)nblk;
+    float dev = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        const float dl = ts[b].x - mean;
+        dev = __builtin_fmaf(dl, dl, dev);
+    }
+    rstd = rsqrtf((sM2 + blkw * dev) / (blkw * (float)nblk) + eps);
+}
+
+// (mean, M2) of the 32 values of one row that lanes (r, 0) and (r, 1) hold between them, 16 each
+__device__ __forceinline__ float2 lnf_block_stats(const f32x16& v) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    const float m16 = s * (1.f / 16.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float dl = v[i] - m16;
+        m2 = __builtin_fmaf(dl, dl, m2);
+    }
+    const float om = __shfl_xor(m16, 32), om2 = __shfl_xor(m2, 32);
+    const float dm = m16 - om;
+    return make_float2(0.5f * (m16 + om), m2 + om2 + 8.f * dm * dm);   // n_a n_b / (n_a + n_b) = 8
+}
+
+__host__ __device__ inline int ws_grid(int M, int N, int NB, int splits) {
+    const int mt = (M + 63) / 64, nct = (N + 64 * NB - 1) / (64 * NB);
+    return (nct * splits * mt + 7) / 8 * 8;
+}
+
 
 // Epilogue of the LDS-DMA GEMMs.  Lane (r, h) holds, for its token row, features 32 b + 8 g + 4 h + 0..3 in
 // acc[b][4g..4g+3].  Each wave transposes its own 32 x 128 tile through its own 16-row LDS strip (no cross-wave
@@ -154,6 +207,111 @@ __device__ __forceinline__ void wl_epilogue(const GemmWlParams& p, const f32x16 
 #else
                 *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
 #endif
+            }
+        }
+    }
+}
+
+// The same epilogue with a LayerNorm folded in (big-batch form of gemm_nt_ws_kernel's forms A and B, see "LayerNorm folded
+// into its consumers" below): after the transposition a half wave holds one complete 128-column row of the tile, four
+// values per lane, so
+//   form A (p.fold_s): C = act(rstd (acc - mean s[n]) + bias[n]) — the input rows' LayerNorm, its gamma folded into the image;
+//   form B (p.ts_out): C = acc + bias + R with R plain (p.R) or the LayerNorm of p.Ry recomputed per element, and the
+//           (mean, M2) of each written row's 128 columns left in ts_out — two 32-lane reductions per row, eight rows'
+//           chains side by side.
+// Per-row (mean, rstd) of the pending LayerNorm come from lnf_finalize_kernel's array, DMA'd into LDS behind the ring by the
+// kernel's first instructions (a plain load in front of the epilogue cost 3 us per tile: two dependent round trips).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {   // v of the lane the DPP control selects (all rows, all banks)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes of this lane's half; every lane gets the sum
+    v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+    v += dpp_f32<0x141>(v);   // row_half_mirror: ... of its 8
+    v += dpp_f32<0x140>(v);   // row_mirror: ... of its row of 16
+    return v + __shfl_xor(v, 16);   // the other row of the half (one ds_bpermute instead of five)
+}
+
+__device__ __forceinline__ void wl_epilogue_lnf(const GemmWlParams& p, const f32x16 (&acc)[4], char* smem, const float2* rowst_all,
+                                                int m0, int n0, int wave, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    float* Cs = reinterpret_cast<float*>(smem) + wave * 16 * 132;
+    const float2* rowst = rowst_all + wave * 32;   // [32] (mean, rstd) of this wave's rows (DMA-filled at the kernel's start)
+    const int c4 = lane & 31;
+    const int n = n0 + 4 * c4;
+    const bool n_ok = n < p.N;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = bv, gv = bv, ev = bv;
+    if (p.bias && n_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.fold_s && n_ok) sv = *reinterpret_cast<const f32x4*>(p.fold_s + n);
+    if (p.Ry && n_ok) {
+        gv = *reinterpret_cast<const f32x4*>(p.ln_g + n);
+        ev = *reinterpret_cast<const f32x4*>(p.ln_b + n);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        if ((r >> 4) == hh) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(&Cs[(r & 15) * 132 + b * 32 + 8 * g + 4 * h]) = v;
+                }
+        }
+        f32x4 vals[8];
+        float rsum[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = (lane >> 5) + 2 * i;                       // row of the strip
+            const int m = m0 + wave * 32 + hh * 16 + lr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lr * 132 + 4 * c4]);
+            const bool ok = m < p.M && n_ok;
+            float2 st = make_float2(0.f, 1.f);
+            if (p.rs_in) st = rowst[hh * 16 + lr];
+            if (p.fold_s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = apply_act(__builtin_fmaf(st.y, v[e], __builtin_fmaf(-st.x * st.y, sv[e], bv[e])), p.act);
+            } else {
+                v += bv;
+                if (ok) {
+                    if (p.Ry) {
+                        const f32x4 y4 = *reinterpret_cast<const f32x4*>(p.Ry + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += __builtin_fmaf((y4[e] - st.x) * st.y, gv[e], ev[e]);
+                    } else if (p.R) {
+                        v += *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+                    }
+                }
+            }
+            if (ok) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (!n_ok) v = f32x4{0.f, 0.f, 0.f, 0.f};   // (N % 128 != 0 only: such a tile's statistics would be short — the host does not ask)
+            vals[i] = v;
+            rsum[i] = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        if (p.ts_out) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rsum[i] = half_wave_sum(rsum[i]) * (1.f / 128.f);   // the row's mean over the tile
+            float m2[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dl = vals[i][e] - rsum[i];
+                    a = __builtin_fmaf(dl, dl, a);
+                }
+                m2[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m2[i] = half_wave_sum(m2[i]);
+            if (c4 == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = m0 + wave * 32 + hh * 16 + (lane >> 5) + 2 * i;
+                    if (m < p.M) p.ts_out[(size_t)m * (p.N >> 7) + (n0 >> 7)] = make_float2(rsum[i], m2[i]);
+                }
             }
         }
     }
@@ -247,6 +405,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wl_kernel(const GemmWlParams p
     const int sw = (my_row >> 2) & 3;
     const int a_off0 = my_row * 64 + (((2 * h) ^ sw) << 4), a_off1 = my_row * 64 + (((2 * h + 1) ^ sw) << 4);
 
+    if (p.rs_in) {   // (mean, rstd) of this wave's 32 rows: 64 dwords, one 4-byte DMA per lane, the oldest of the wave's DMAs
+        int mrow = m0 + wave * 32 + (lane >> 1);
+        mrow = mrow < p.M ? mrow : p.M - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const float*>(p.rs_in + mrow) + (lane & 1)),
+                                         (__attribute__((address_space(3))) void*)(smem + Geo::ROWST + wave * 256), 4, 0, 0);
+    }
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) issue_stage(st < n_stages ? st : n_stages - 1);
 
@@ -380,7 +544,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wl_kernel(const GemmWlParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped re-loads of the last stages
     __builtin_amdgcn_s_barrier();                       // every wave is done with the ring: it carries the output now
 
-    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+    if (p.fold_s || p.ts_out) wl_epilogue_lnf(p, acc, smem, reinterpret_cast<const float2*>(smem + Geo::ROWST), m0, n0, wave, lane);
+    else wl_epilogue(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ---- role-split rings --------------------------------------------------------------------------------------------
@@ -513,7 +678,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wl3_kernel(const GemmWlParams 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+    if (p.fold_s || p.ts_out) wl_epilogue_lnf(p, acc, smem, reinterpret_cast<const float2*>(smem + Geo::ROWST), m0, n0, wave, lane);
+    else wl_epilogue(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ---- software-pipelined form --------------------------------------------------------------------------------------
@@ -679,7 +845,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_wl4_kernel(const GemmWlParams 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    wl_epilogue(p, acc, smem, m0, n0, wave, lane);
+    if (p.fold_s || p.ts_out) wl_epilogue_lnf(p, acc, smem, reinterpret_cast<const float2*>(smem + Geo::ROWST), m0, n0, wave, lane);
+    else wl_epilogue(p, acc, smem, m0, n0, wave, lane);
 }
 
 // ---- small batches (the query encoder: 32 queries ~ 450 tokens) ------------------------------------------------------
@@ -748,44 +915,6 @@ struct GemmWsParams {
 //   * a GEMM whose RESIDUAL is LN(y) recomputes it per element in its epilogue: (y - mean) rstd gamma[n] + beta[n].
 // Per row, mean and rstd come from combining the H / 32 block statistics (lnf_row_stats): ~50 loads per lane, issued
 // at the top of the epilogue.
-__device__ __forceinline__ void lnf_row_stats(const float2* ts, int nblk, float eps, float& mean, float& rstd) {
-    float sm = 0.f, sM2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float2 q = ts[b];
-        sm += q.x;
-        sM2 += q.y;
-    }
-    mean = sm / (float)nblk;
-    float dev = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        const float dl = ts[b].x - mean;
-        dev = __builtin_fmaf(dl, dl, dev);
-    }
-    rstd = rsqrtf((sM2 + 32.f * dev) / (32.f * (float)nblk) + eps);
-}
-
-// (mean, M2) of the 32 values of one row that lanes (r, 0) and (r, 1) hold between them, 16 each
-__device__ __forceinline__ float2 lnf_block_stats(const f32x16& v) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += v[i];
-    const float m16 = s * (1.f / 16.f);
-    float m2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float dl = v[i] - m16;
-        m2 = __builtin_fmaf(dl, dl, m2);
-    }
-    const float om = __shfl_xor(m16, 32), om2 = __shfl_xor(m2, 32);
-    const float dm = m16 - om;
-    return make_float2(0.5f * (m16 + om), m2 + om2 + 8.f * dm * dm);   // n_a n_b / (n_a + n_b) = 8
-}
-
-__host__ __device__ inline int ws_grid(int M, int N, int NB, int splits) {
-    const int mt = (M + 63) / 64, nct = (N + 64 * NB - 1) / (64 * NB);
-    return (nct * splits * mt + 7) / 8 * 8;
-}
-
 // Sixteen waves per workgroup.  With four (one per SIMD) a stage ran strictly in order — DMA issues, LDS reads, the
 // conversion, three MFMAs per K-step, four K-steps — about 1 us per stage whatever the ring depth or the L2 placement
 // (kernel traces, scripts/prof_encoder.py): issue latency, not bandwidth.  Here wave (g, quadrant) takes K-step g of

@@ -58,9 +58,12 @@ struct rag_bert {
     // vectors s[n] = sum_k W'[n][k] and bias2 = bias + W beta.  Built at create when the model qualifies (lnf_ok).
     std::vector<_Float16*> wfold;     // [2 l] QKV, [2 l + 1] feed-forward input
     std::vector<float*> fold_s, fold_b;
-    bool lnf_ok = false;
+    bool lnf_ok = false;          // the query-encoder form (<= 1024 tokens) is on: RAG_AMD_ENCODER_LN_FOLD=1
+    bool lnf_built = false;       // the folded images exist
+    bool lnf_big = false;         // the big-batch form (> 1024 tokens, gemm_nt_wl_kernel) is on: the default, RAG_AMD_LN_FOLD=0 turns it off
     float* y1 = nullptr;              // [ws_tokens][H]: the second pre-LayerNorm row buffer (x is the first)
     float2 *ts_a = nullptr, *ts_b = nullptr;   // [ws_tokens][H / 32] block statistics of x / y1
+    float2 *rs_a = nullptr, *rs_b = nullptr;   // [ws_tokens] finished (mean, rstd) of x / y1 (big-batch form)
     unsigned* tile_ctr = nullptr;     // arrival counters of the split-K tiles (zero between launches)
     uint32_t* range_pin = nullptr;    // pinned host word the GEMM kernels write themselves (posted store): a two-plane
                                       // GEMM met |a| >= 65504 (or a weight did, at creation); read after a sync
@@ -151,9 +154,11 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
             if (*b) (void)hipFree(*b);
             *b = nullptr;
         }
-        if (h->ts_a) (void)hipFree(h->ts_a);
-        if (h->ts_b) (void)hipFree(h->ts_b);
-        h->ts_a = h->ts_b = nullptr;
+        float2** tsb[] = {&h->ts_a, &h->ts_b, &h->rs_a, &h->rs_b};
+        for (float2** b : tsb) {
+            if (*b) (void)hipFree(*b);
+            *b = nullptr;
+        }
         h->ws_tokens = 0;
         const long long t = (tokens + tokens / 8 + 31) & ~31LL;   // (whole 32-token row blocks: the tiled layout's unit)
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->x), (size_t)t * c.hidden * sizeof(float)));
@@ -162,11 +167,17 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->qkv), (size_t)t * 3 * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ctx), (size_t)t * c.hidden * sizeof(float)));
         RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ffn), (size_t)t * c.intermediate * sizeof(float)));
-        if (h->lnf_ok) {
-            const long long ts_rows = std::min<long long>(t, 1056);   // the folded-LayerNorm path takes <= 1024 tokens
-            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y1), (size_t)ts_rows * c.hidden * sizeof(float)));
-            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_a), (size_t)ts_rows * (c.hidden / 32) * sizeof(float2)));
-            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_b), (size_t)ts_rows * (c.hidden / 32) * sizeof(float2)));
+        if (h->lnf_ok || h->lnf_big) {
+            // block statistics: 32-column blocks for up to 1024 tokens (query encoder), 128-column blocks beyond
+            const long long ts_rows = std::min<long long>(t, 1056);
+            const size_t ts_n = std::max<size_t>((size_t)ts_rows * (c.hidden / 32), (size_t)t * ((c.hidden + 127) / 128));
+            if (h->lnf_ok) RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y1), (size_t)ts_rows * c.hidden * sizeof(float)));
+            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_a), ts_n * sizeof(float2)));
+            RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_b), ts_n * sizeof(float2)));
+            if (h->lnf_big) {
+                RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rs_a), (size_t)t * sizeof(float2)));
+                RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->rs_b), (size_t)t * sizeof(float2)));
+            }
         }
         h->ws_tokens = t;
     }
@@ -449,6 +460,32 @@ int launch_ws_lnf_b(rag_bert* h, const float* A, int K, const _Float16* img, con
     return launch_ws(g, sp, h->n_cus, st, h->background);
 }
 
+// Big-batch forms (gemm_nt_wl_kernel<2, 1, 3> with wl_epilogue_lnf): statistics per (row, 128-column tile).
+int launch_wl_lnf_a(rag_bert* h, const float* Y, const float2* rs_in, const _Float16* img, const float* s_vec, const float* b2,
+                    float* C, int M, int N, int K, int act, uint32_t* range_flag, hipStream_t st) {
+    ragb::GemmWlParams g{Y, img, b2, nullptr, C, M, N, K, K, 0, N, act, range_flag};
+    g.rs_in = rs_in;
+    g.fold_s = s_vec;
+    return launch_wl<2, 1, 3, false>(g, st);
+}
+
+int launch_wl_lnf_b(rag_bert* h, const float* A, int K, const _Float16* img, const float* bias, const float* R_plain,
+                    const float* Ry, const float2* rs_in, const float* ln_g, const float* ln_b, float* Yout, float2* ts_out,
+                    float2* rs_out, int M, int N, uint32_t* range_flag, hipStream_t st) {
+    ragb::GemmWlParams g{A, img, bias, R_plain, Yout, M, N, K, K, N, N, ragb::ACT_NONE, range_flag};
+    g.rs_in = Ry ? rs_in : nullptr;
+    g.Ry = Ry;
+    g.ln_g = ln_g;
+    g.ln_b = ln_b;
+    g.ts_out = ts_out;
+    int rc = launch_wl<2, 1, 3, false>(g, st);
+    if (rc) return rc;
+    // the rows' (mean, rstd) from their N / 128 tile statistics, for the kernels that read them next
+    ragb::lnf_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st>>>(ts_out, N / 128, 128.f, h->cfg.ln_eps, rs_out, M);
+    RAGC_HIP_TRY(hipGetLastError());
+    return RAG_OK;
+}
+
 size_t out_elems(const rag_bert_config& c, int out_kind, long long nseq, long long tokens) {
     switch (out_kind) {
         case RAG_BERT_OUT_MEAN:
@@ -560,7 +597,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             else
                 attention_mfma_kernel<64><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
             RAGC_HIP_TRY(hipGetLastError());
-            gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps);
+            gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps, 32);
             RAGC_HIP_TRY(hipGetLastError());
             const WRef w1{lw[2], h->wx2[at + 1], nullptr, nullptr, range_flag, h->background};
             const WRef w2{lw[6], h->wx2[at + 2], nullptr, nullptr, range_flag, h->background};
@@ -589,13 +626,83 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         rc = launch_ws_lnf_b(h, h->ffn, I, h->wx2[at + 3], lw[9], h->y1, h->ts_b, lw[4], lw[5], h->x, h->ts_a, T, H, range_flag, st);
         if (rc) return rc;
         if (l == c.n_layers - 1) {   // the encoder's last LayerNorm, materialised once for the output stage
-            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y1, T, H, c.ln_eps);
+            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y1, T, H, c.ln_eps, 32);
             RAGC_HIP_TRY(hipGetLastError());
             xfinal = h->y1;
         }
     }
 
-    for (int l = 0; !lnf && l < c.n_layers; ++l) {
+    // Big batches in the default mode (> 1024 tokens, two-plane GEMMs): the same folding without any hand-off — these GEMMs
+    // are not split along K, so the epilogue of the GEMM that writes a pre-LayerNorm sum leaves its rows' statistics per
+    // 128-column tile and the GEMMs that read it apply them (wl_epilogue_lnf).  Ten of a six-layer cross-encoder's twelve
+    // LayerNorm passes (0.55 GB read + written each at 178 k tokens) disappear; layer 0 reads the materialised embeddings.
+    const bool lnfb = h->lnf_big && h->lnf_built && T > 1024 && !tiled && !h->force_x6 && h->weights_fit_f16 &&
+                      !h->valu_attention && c.gemm_mode == RAG_GEMM_F32 && H % 128 == 0 && (H % 16) == 0 && (I % 16) == 0 &&
+                      h->ts_a != nullptr;
+    for (int l = 0; lnfb && l < c.n_layers; ++l) {
+        const float* const* lw = w + kEmbEntries + kPerLayer * l;
+        const bool pending = l > 0;   // x holds a pre-LayerNorm sum (statistics in ts_a) instead of a finished row
+        const float* g_prev = pending ? (lw - kPerLayer)[10] : nullptr;
+        const float* b_prev = pending ? (lw - kPerLayer)[11] : nullptr;
+        const size_t at = (size_t)4 * l;
+        const WRef wq{lw[0], h->wx2[at + 0], nullptr, nullptr, range_flag, h->background};
+        const bool last_first_only = first_only_out && l == c.n_layers - 1 && nseq < T;
+        if (pending)
+            rc = launch_wl_lnf_a(h, h->x, h->rs_a, h->wfold[2 * l], h->fold_s[2 * l], h->fold_b[2 * l], h->qkv, T, 3 * H, H, ACT_NONE,
+                                 range_flag, st);
+        else
+            rc = launch_gemm(h->x, H, wq, H, lw[1], nullptr, 0, h->qkv, 3 * H, T, 3 * H, H, ACT_NONE, st, h->n_cus);
+        if (rc) return rc;
+        if (last_first_only) {
+            const dim3 fgrid(1, heads, nseq);
+            if (dh == 32)
+                attention_mfma_kernel<32><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
+            else
+                attention_mfma_kernel<64><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
+            RAGC_HIP_TRY(hipGetLastError());
+            if (pending) {
+                gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps, 128);
+            } else {
+                const int total = nseq * H;
+                gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
+            }
+            RAGC_HIP_TRY(hipGetLastError());
+            const WRef w1{lw[2], h->wx2[at + 1], nullptr, nullptr, range_flag, h->background};
+            const WRef w2{lw[6], h->wx2[at + 2], nullptr, nullptr, range_flag, h->background};
+            const WRef w3{lw[8], h->wx2[at + 3], nullptr, nullptr, range_flag, h->background};
+            rc = launch_gemm_ln(h->ctx, H, w1, H, lw[3], h->pooled, h->y, lw[4], lw[5], h->pooled, nseq, H, H, c.ln_eps, h->n_cus, st);
+            if (rc) return rc;
+            rc = launch_gemm(h->pooled, H, w2, H, lw[7], nullptr, 0, h->ffn, I, nseq, I, H, act, st, h->n_cus);
+            if (rc) return rc;
+            rc = launch_gemm_ln(h->ffn, I, w3, I, lw[9], h->pooled, h->y, lw[10], lw[11], h->pooled, nseq, H, I, c.ln_eps, h->n_cus, st);
+            if (rc) return rc;
+            compact = true;
+            break;
+        }
+        if (dh == 32)
+            attention_mfma_kernel<32><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        else
+            attention_mfma_kernel<64><<<mgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale);
+        RAGC_HIP_TRY(hipGetLastError());
+        // y1 = ctx Wo^T + bo + (x | LN_prev(x)) into h->y, statistics to ts_b
+        rc = launch_wl_lnf_b(h, h->ctx, H, h->wx2[at + 1], lw[3], pending ? nullptr : h->x, pending ? h->x : nullptr, h->rs_a, g_prev,
+                             b_prev, h->y, h->ts_b, h->rs_b, T, H, range_flag, st);
+        if (rc) return rc;
+        rc = launch_wl_lnf_a(h, h->y, h->rs_b, h->wfold[2 * l + 1], h->fold_s[2 * l + 1], h->fold_b[2 * l + 1], h->ffn, T, I, H, act,
+                             range_flag, st);
+        if (rc) return rc;
+        // x = ffn W2^T + b2 + LN1(y1): the next layer's pre-LayerNorm input, statistics to ts_a / rs_a
+        rc = launch_wl_lnf_b(h, h->ffn, I, h->wx2[at + 3], lw[9], nullptr, h->y, h->rs_b, lw[4], lw[5], h->x, h->ts_a, h->rs_a, T, H,
+                             range_flag, st);
+        if (rc) return rc;
+        if (l == c.n_layers - 1) {   // the last LayerNorm, materialised once for the output stage
+            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y, T, H, c.ln_eps, 128);
+            RAGC_HIP_TRY(hipGetLastError());
+            xfinal = h->y;
+        }
+    }
+
+    for (int l = 0; !lnf && !lnfb && l < c.n_layers; ++l) {
         const float* const* lw = w + kEmbEntries + kPerLayer * l;
         const int wsrc[4] = {0, 2, 6, 8};  // qkv_w, attn_out_w, ffn_in_w, ffn_out_w in the layer's table
         auto wref = [&](int i) -> WRef {
@@ -854,7 +961,7 @@ int build_folded(rag_bert* h) {
         *h->range_pin = 0;
         return RAG_OK;
     }
-    h->lnf_ok = true;
+    h->lnf_built = true;
     return RAG_OK;
 }
 }  // namespace
@@ -1126,11 +1233,17 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
         // workgroup to another inside a launch costs two to three memory-side round trips (agent-scope stores, the arrival
         // atomic, agent-scope loads: 10-19 us per GEMM) — more than the kernel boundary and the 6 us LayerNorm launch it
         // replaces (bge-base, 32 queries: 1.37 ms folded against 1.00 ms).
+        // The big-batch form has no hand-off (no split-K there): the GEMM epilogues leave the statistics and apply them —
+        // on by default (RAG_AMD_LN_FOLD=0: the separate LayerNorm passes, A/B checks).
         const char* lf = getenv("RAG_AMD_ENCODER_LN_FOLD");
-        if (lf && *lf == '1' && (rc = build_folded(h))) {
+        const char* lb = getenv("RAG_AMD_LN_FOLD");
+        const bool want_small = lf && *lf == '1', want_big = !(lb && *lb == '0') && c.hidden % 128 == 0;
+        if ((want_small || want_big) && (rc = build_folded(h))) {
             rag_bert_destroy(h);
             return rc;
         }
+        h->lnf_ok = h->lnf_built && want_small;
+        h->lnf_big = h->lnf_built && want_big;
     }
     *out = h;
     return RAG_OK;
@@ -1160,7 +1273,7 @@ extern "C" int rag_bert_destroy(rag_bert* h) {
             if (p) (void)hipFree(p);
         for (float* p : h->fold_b)
             if (p) (void)hipFree(p);
-        void* lptrs[] = {h->y1, h->ts_a, h->ts_b, h->tile_ctr};
+        void* lptrs[] = {h->y1, h->ts_a, h->ts_b, h->rs_a, h->rs_b, h->tile_ctr};
         for (void* p : lptrs)
             if (p) (void)hipFree(p);
         for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
