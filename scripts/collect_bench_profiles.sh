@@ -6,7 +6,7 @@
 # The summaries to be judged are then copied into profiles/ by hand (profiles/README.md).
 set -eu -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)   # the checkout this script lives in (no harness variable needed)
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 python "$ROOT/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"

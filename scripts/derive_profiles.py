@@ -87,8 +87,32 @@ if os.path.exists(pm):
                            "fp16_products_per_fp32_product": 3, "fp32_equivalent_peak_tflops_at_2.4ghz": 2500.0 / 3},
                "source": f"scripts/prof_rerank_pmc.sh {tag}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace "
                          "-- python3 scripts/prof_rerank.py (counters in their own pass)",
-               "note": "the same GEMMs took 6 bf16 MFMAs per fragment pair in round 2 (41 % utilisation): half the matrix work in 0.63x the "
-                       "time lowers the utilisation figure while the pass gets faster; the kernel is bound by the L2 -> LDS operand stream "
-                       "(scripts/exp/gemm_wl_bench.hip ablations)"},
+               "note": "round 4: ten of the pass's twelve LayerNorm passes are folded into these GEMMs' epilogues (tile statistics out, "
+                       "per-row LayerNorm in); the K loop is round 3's — bound by the L2 -> LDS operand stream (scripts/exp/gemm_wl_bench.hip ablations)"},
               open(os.path.join(out_dir, f"{tag}_rerank_gemm_mfma_util.json"), "w"), indent=1)
+# ---- MFMA utilisation of the query encoder's small-batch GEMMs
+pe = os.path.join(root, "pmc_encoder", "enc_counter_collection.csv")
+if os.path.exists(pe):
+    acc = collections.defaultdict(float)
+    n, tms = 0, 0.0
+    seen = set()
+    for r in rows(pe):
+        if "gemm_nt_ws_kernel" not in r["Kernel_Name"]:
+            continue
+        acc[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"]); n += 1
+            tms += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    busy_per_simd = acc["SQ_VALU_MFMA_BUSY_CYCLES"] / (256 * 4)
+    gpu_cycles = acc["GRBM_GUI_ACTIVE"] / 8.0
+    json.dump({"workload": "query encoder, bge-base-en-v1.5 architecture (12x768), 32 queries = 447 packed tokens, default GEMM mode",
+               "kernel": "gemm_nt_ws_kernel<1|2, 4> (64-row tiles, sixteen waves, split-K for the N = H GEMMs)",
+               "launches": n, "SQ_VALU_MFMA_BUSY_CYCLES_sum": acc["SQ_VALU_MFMA_BUSY_CYCLES"],
+               "GRBM_GUI_ACTIVE_sum_over_8_xcds": acc["GRBM_GUI_ACTIVE"], "kernel_time_total_ms": tms,
+               "derived": {"mfma_busy_cycles_per_simd": busy_per_simd, "gpu_cycles": gpu_cycles,
+                           "mfma_utilisation": busy_per_simd / gpu_cycles if gpu_cycles else None},
+               "source": f"scripts/prof_encoder_pmc.sh {tag}: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- "
+                         "python3 scripts/prof_encoder.py (counters in their own pass)",
+               "note": "a 447-token batch is launch- and operand-latency-bound (84 dependent launches of 5-26 us); the matrix pipe idles"},
+              open(os.path.join(out_dir, f"{tag}_encoder_mfma_util.json"), "w"), indent=1)
 print("ok")
