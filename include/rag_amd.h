@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 6
+#define RAG_AMD_ABI_VERSION 5
 
 /* status codes */
 #define RAG_OK 0
@@ -240,18 +240,12 @@ int rag_merge_topk_packed_device(int32_t device, int32_t metric, int32_t n_shard
  * caller reads ONE word back, not one per rank).  host_mirror (NULL, or pinned host memory the device can write:
  * hipHostMalloc / torch pin_memory, 8-byte aligned, laid out like ONE shard's block — ids at 0, scores at
  * scores_offset_bytes, the OR-ed word at flag_offset_bytes) receives the same result from the merge kernel itself:
- * the batch then needs no read-back copy, only a wait for `stream` — or, with done_host (NULL, or nq 32-bit words of pinned
- * host memory) and done_seq (> 0, different from the previous batch's on these words), not even that: query q's
- * workgroup stores done_seq into done_host[q] behind its last result store, and rag_wait_done polls for the nq stamps. */
+ * the batch then needs no read-back copy, only a wait for `stream`. */
 int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t n_shards, int32_t nq, int32_t k,
                                          const void* packed_dev, int64_t shard_stride_bytes,
                                          int64_t scores_offset_bytes, int64_t flag_offset_bytes,
                                          float* out_scores_dev, int64_t* out_ids_dev, uint32_t* any_flag_dev,
-                                         void* host_mirror, uint32_t* done_host, uint32_t done_seq, void* stream);
-
-/* Spin until done_host[0 .. n) all hold `seq` (the stamps a merge with done_host leaves): the results are then in the
- * host mirror.  timeout_us < 0: wait for ever.  RAG_ERR_STATE on timeout.  (Host memory only: never touches the device.) */
-int rag_wait_done(const uint32_t* done_host, int32_t n, uint32_t seq, int64_t timeout_us);
+                                         void* host_mirror, void* stream);
 
 
 /* ---- IVFFlat `nprobe` mode (optional) --------------------------------------------------------------------- */
@@ -335,16 +329,14 @@ int rag_pack_layout(int32_t nq, int32_t k, int64_t* scores_offset, int64_t* flag
  *   -> ncclAllGather(pack_dev -> gathered_dev: world blocks)
  *   -> rag_merge_topk_packed_flagged_device(gathered_dev) into out_scores_dev / out_ids_dev / any_flag_dev and, when
  *      host_mirror is given (pinned, one block's layout), into host memory by the merge kernel itself.
- * done_host / done_seq: completion stamps, as for rag_merge_topk_packed_flagged_device (the caller then polls
- * rag_wait_done instead of waiting for a stream).
  * comm_stream (NULL: `stream`) may name a second stream for the all-gather and the merge: they then start when the
  * local search has finished on `stream` (an event) and run BESIDE the next batch's local search — over xGMI the
  * collective's latency leaves the step time.  The caller waits for comm_stream (or `stream`) before reading results.
  * Replaces, for a sharded index, what faiss_store.py:152 does in one process. */
 int rag_index_search_gather_device(rag_index* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k,
                                    int32_t mode, void* pack_dev, void* gathered_dev, float* out_scores_dev,
-                                   int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror, uint32_t* done_host,
-                                   uint32_t done_seq, void* stream, void* comm_stream);
+                                   int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror, void* stream,
+                                   void* comm_stream);
 
 /* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
 

@@ -227,8 +227,7 @@ def signatures() -> dict:
         "rag_merge_topk_packed_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                    vp, C.c_int64, C.c_int64, vp, vp, vp]),
         "rag_merge_topk_packed_flagged_device": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                                           vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, C.c_uint32, vp]),
-        "rag_wait_done": (C.c_int, [vp, C.c_int32, C.c_uint32, C.c_int64]),
+                                                           vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]),
         "rag_ivf_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]),
         "rag_ivf_destroy": (C.c_int, [vp]),
         "rag_ivf_set_lists": (C.c_int, [vp, f32p, C.c_int64, f32p, i64p, i64p]),
@@ -247,7 +246,7 @@ def signatures() -> dict:
         "rag_comm_wait_head": (C.c_int, [vp, C.c_uint64, C.c_int64, i64p]),
         "rag_pack_layout": (C.c_int, [C.c_int32, C.c_int32, i64p, i64p, i64p]),
         "rag_index_search_gather_device": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp,
-                                                     vp, C.c_uint32, vp, vp]),
+                                                     vp, vp]),
         "rag_bert_weight_count": (C.c_int32, [C.POINTER(BertConfigStruct)]),
         "rag_bert_create": (C.c_int, [C.POINTER(BertConfigStruct), C.POINTER(vp), C.c_int32, C.c_int32,
                                       C.POINTER(vp)]),

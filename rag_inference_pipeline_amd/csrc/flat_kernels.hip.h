@@ -871,10 +871,6 @@ struct MergeOut {
     float* scores_host;
     long long* ids_host;
     uint32_t* any_flag_host;
-    // optional completion stamps in pinned host memory: query q's workgroup stores done_seq into done_host[q] behind its last
-    // result store (system-scope fence in between), so the host can poll for the batch instead of synchronising a stream
-    uint32_t* done_host;
-    uint32_t done_seq;
 };
 
 // Wave-wide 64-bit max on the DPP cross-lane paths (quad permutes, row mirrors, row broadcasts): a
@@ -1026,10 +1022,6 @@ __global__ __launch_bounds__(64 * WAVES) void tournament_merge_kernel(const Src 
         }
         if (out.last_key && round == k - 1) out.last_key[q] = bm;
     });
-    if (tid == 0 && out.done_host) {   // thread 0 wrote every result of this query itself
-        __threadfence_system();
-        __hip_atomic_store(out.done_host + q, out.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 // ---- two-stage exact search: screening copy, certificate, exact second stage ---------------------

@@ -4,7 +4,6 @@
 #include "../../include/rag_amd.h"
 
 #include <hip/hip_runtime.h>
-#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1292,8 +1291,7 @@ namespace {
 int merge_shards(int device, int metric, int n_shards, int nq, int k, const float* scores, long long score_stride,
                  const long long* ids, long long id_stride, float* out_s, long long* out_i, void* stream,
                  const uint32_t* flags = nullptr, long long flag_stride = 0, uint32_t* any_flag = nullptr,
-                 float* host_s = nullptr, long long* host_i = nullptr, uint32_t* host_any = nullptr,
-                 uint32_t* done_host = nullptr, uint32_t done_seq = 0) {
+                 float* host_s = nullptr, long long* host_i = nullptr, uint32_t* host_any = nullptr) {
     using namespace ragk;
     if (n_shards <= 0 || nq < 0 || k <= 0 || !scores || !ids || !out_s || !out_i)
         return fail(RAG_ERR_INVALID_ARG, "bad arguments");
@@ -1307,7 +1305,7 @@ int merge_shards(int device, int metric, int n_shards, int nq, int k, const floa
     DeviceGuard g(device);
     ShardListSrc src{scores, ids, score_stride, id_stride, k, metric};
     MergeOut mo{out_s, out_i, nullptr, k, nullptr, 0, metric, 1, nullptr, 0, flags, flag_stride, n_shards, any_flag,
-                host_s, host_i, host_any, done_host, done_seq};
+                host_s, host_i, host_any};
     const int look = merge_look(n_shards, k, k);
     launch_merge(src, n_shards, nq, k, look, mo, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1339,8 +1337,7 @@ extern "C" int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metr
                                                     const void* packed_dev, int64_t shard_stride_bytes,
                                                     int64_t scores_offset_bytes, int64_t flag_offset_bytes,
                                                     float* out_scores_dev, int64_t* out_ids_dev,
-                                                    uint32_t* any_flag_dev, void* host_mirror, uint32_t* done_host,
-                                                    uint32_t done_seq, void* stream) {
+                                                    uint32_t* any_flag_dev, void* host_mirror, void* stream) {
     if (!packed_dev || shard_stride_bytes % 8 || scores_offset_bytes % 4 || shard_stride_bytes <= 0)
         return fail(RAG_ERR_INVALID_ARG, "packed layout must keep ids 8-byte and scores 4-byte aligned");
     if (!any_flag_dev || flag_offset_bytes < 0 || flag_offset_bytes % 4 || flag_offset_bytes + 4 > shard_stride_bytes)
@@ -1348,8 +1345,6 @@ extern "C" int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metr
     if (nq <= 0) return fail(RAG_ERR_INVALID_ARG, "nq must be positive (the flags are reduced by query 0's workgroup)");
     if (host_mirror && (reinterpret_cast<uintptr_t>(host_mirror) % 8))
         return fail(RAG_ERR_INVALID_ARG, "host mirror must be 8-byte aligned");
-    if (done_host && (!host_mirror || done_seq == 0))
-        return fail(RAG_ERR_INVALID_ARG, "completion stamps need a host mirror and a sequence number > 0");
     const char* base = static_cast<const char*>(packed_dev);
     char* hm = static_cast<char*>(host_mirror);
     return merge_shards(device, metric, n_shards, nq, k, reinterpret_cast<const float*>(base + scores_offset_bytes),
@@ -1357,25 +1352,7 @@ extern "C" int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metr
                         out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), stream,
                         reinterpret_cast<const uint32_t*>(base + flag_offset_bytes), shard_stride_bytes / 4, any_flag_dev,
                         hm ? reinterpret_cast<float*>(hm + scores_offset_bytes) : nullptr, reinterpret_cast<long long*>(hm),
-                        hm ? reinterpret_cast<uint32_t*>(hm + flag_offset_bytes) : nullptr, done_host, done_seq);
-}
-
-extern "C" int rag_wait_done(const uint32_t* done_host, int32_t n, uint32_t seq, int64_t timeout_us) {
-    if (!done_host || n <= 0) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
-    timespec t0;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    int done = 0;
-    for (long long spins = 0;; ++spins) {
-        while (done < n && __atomic_load_n(done_host + done, __ATOMIC_ACQUIRE) == seq) ++done;
-        if (done == n) return RAG_OK;
-        if ((spins & 1023) == 1023 && timeout_us >= 0) {
-            timespec t;
-            clock_gettime(CLOCK_MONOTONIC, &t);
-            const long long us = (t.tv_sec - t0.tv_sec) * 1000000LL + (t.tv_nsec - t0.tv_nsec) / 1000;
-            if (us > timeout_us) return fail(RAG_ERR_STATE, "batch %u not complete within %lld us (%d of %d queries)", seq, (long long)timeout_us, done, n);
-        }
-        __builtin_ia32_pause();
-    }
+                        hm ? reinterpret_cast<uint32_t*>(hm + flag_offset_bytes) : nullptr);
 }
 
 
@@ -1393,7 +1370,7 @@ extern "C" int rag_pack_layout(int32_t nq, int32_t k, int64_t* scores_offset, in
 extern "C" int rag_index_search_gather_device(rag_index* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k,
                                               int32_t mode, void* pack_dev, void* gathered_dev, float* out_scores_dev,
                                               int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror,
-                                              uint32_t* done_host, uint32_t done_seq, void* stream, void* comm_stream) {
+                                              void* stream, void* comm_stream) {
     if (!c) return fail(RAG_ERR_INVALID_ARG, "null communicator");
     if (nq <= 0) return fail(RAG_ERR_INVALID_ARG, "nq must be positive");
     if (!pack_dev || !gathered_dev || !any_flag_dev) return fail(RAG_ERR_INVALID_ARG, "null pack / gather / flag buffer");
@@ -1427,7 +1404,7 @@ extern "C" int rag_index_search_gather_device(rag_index* h, rag_comm* c, const f
         if (rc) return rc;
     }
     return rag_merge_topk_packed_flagged_device(h->device, h->metric, world, nq, k, gathered_dev, blk, s_off, f_off, out_scores_dev,
-                                                out_ids_dev, any_flag_dev, host_mirror, done_host, done_seq, (void*)cst);
+                                                out_ids_dev, any_flag_dev, host_mirror, (void*)cst);
 }
 
 #include "rag_ivf_host.hip.h"   // the IVFFlat nprobe mode (rag_ivf_*)

@@ -170,15 +170,14 @@ def merge_topk_device(device: int, metric: int, n_shards: int, nq: int, k: int, 
 def merge_topk_packed_flagged_device(device: int, metric: int, n_shards: int, nq: int, k: int, packed_ptr: int,
                                      shard_stride_bytes: int, scores_offset_bytes: int, flag_offset_bytes: int,
                                      out_scores_ptr: int, out_ids_ptr: int, any_flag_ptr: int, host_mirror_ptr: int = 0,
-                                     stream: int = 0, done_ptr: int = 0, done_seq: int = 0) -> None:
+                                     stream: int = 0) -> None:
     """Merge out of the all-gather receive buffer and OR the shards' "not final" words into one device word
     (rag_merge_topk_packed_flagged_device); with `host_mirror_ptr` (pinned host memory, one block's layout) the
     kernel writes the result to the host as well."""
     _native.check(_native.lib().rag_merge_topk_packed_flagged_device(
         int(device), int(metric), int(n_shards), int(nq), int(k), C.c_void_p(packed_ptr), int(shard_stride_bytes),
         int(scores_offset_bytes), int(flag_offset_bytes), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr),
-        C.c_void_p(any_flag_ptr), C.c_void_p(host_mirror_ptr or None), C.c_void_p(done_ptr or None), int(done_seq),
-        C.c_void_p(stream)))
+        C.c_void_p(any_flag_ptr), C.c_void_p(host_mirror_ptr or None), C.c_void_p(stream)))
 
 
 def merge_topk_packed_device(device: int, metric: int, n_shards: int, nq: int, k: int, packed_ptr: int,

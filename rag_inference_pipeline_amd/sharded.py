@@ -99,11 +99,6 @@ class _Slot:
         self.res_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if on_gpu else self.res
         self.host_i, self.host_s, self.host_any = views(self.res_host)
         self.event = torch.cuda.Event() if on_gpu else None
-        # completion stamps of the own-communicator path: the merge kernel's workgroups store `seq` here (pinned), the host
-        # polls them (rag_wait_done) instead of synchronising an event
-        self.done = torch.zeros(nq, dtype=torch.int32).pin_memory() if on_gpu else None
-        self.seq = 0
-        self.polled = False
         if owner.backend != "nccl":
             self.pack_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory() if on_gpu \
                 else torch.empty(nbytes, dtype=torch.uint8)
@@ -111,7 +106,6 @@ class _Slot:
         # the slot's buffers as the C ABI takes them, wrapped once (rag_index_search_gather_device is called per batch)
         self.c_args = tuple(C.c_void_p(t.data_ptr()) for t in (self.pack, self.gathered, self.out_s, self.out_i,
                                                                self.out_any, self.res_host))
-        self.c_done = C.c_void_p(self.done.data_ptr()) if self.done is not None else None
         self.pending: Any = None   # the query tensor of the search in flight (kept alive for a repeat)
         self.repeats = 0           # fp32 repeats this slot has run (tests, stats)
 
@@ -307,18 +301,8 @@ class ShardedFlatIndex:
                                      self._stream())
             s.pack_f.zero_()
 
-    def _wait(self, s: _Slot) -> None:
-        """Host wait for the step enqueued on slot s: the merge kernel's completion stamps (own communicator), else the
-        slot's event."""
-        if s.polled:
-            from . import _native
-            _native.check(_native.lib().rag_wait_done(s.c_done, s.nq, s.seq, 60_000_000))
-        elif s.event is not None:
-            s.event.synchronize()
-
     def _gather_and_merge(self, s: _Slot) -> None:
         torch = self._torch
-        s.polled = False
         self._all_gather(s)
         if self._merge is not None:  # test double: unpack on the host side of the tensor API
             g = s.gathered.view(self.world, s.nbytes)
@@ -360,11 +344,13 @@ class ShardedFlatIndex:
             return
         from . import _native
         cs = self._comm_stream
-        s.seq = s.seq % 0x7FFFFFFF + 1   # never 0, never the previous batch's
-        s.polled = True
         _native.check(_native.lib().rag_index_search_gather_device(
             self.local._handle(), self._comm, C.c_void_p(queries.data_ptr()), s.nq, s.k, int(mode), *s.c_args,
-            s.c_done, s.seq, C.c_void_p(self._stream()), C.c_void_p(cs.cuda_stream) if cs is not None else None))
+            C.c_void_p(self._stream()), C.c_void_p(cs.cuda_stream) if cs is not None else None))
+        if cs is not None:
+            s.event.record(cs)
+        else:
+            s.event.record()
 
     def collect(self, s: _Slot) -> tuple[Any, Any]:
         """Collective: wait for submit()'s search; if some rank's two-stage certificate failed (the same word
@@ -373,10 +359,12 @@ class ShardedFlatIndex:
         `slot.host_i` hold the same values in pinned host memory."""
         if s.pending is None:
             raise RuntimeError("collect() without a submit() in flight on this slot")
-        self._wait(s)
+        if s.event is not None:
+            s.event.synchronize()
         if int(s.host_any[0]) != 0:
             self._step(s, s.pending, SEARCH_EXACT_ONE_PASS)
-            self._wait(s)
+            if s.event is not None:
+                s.event.synchronize()
             s.repeats += 1
             self.repeats += 1
         s.pending = None
@@ -529,12 +517,14 @@ class ShardedFlatIndex:
             nq = min(self.max_batch, nq_total - lo)
             s = self._leader_enqueue(q[lo:lo + nq], k, False, None)
             try:
-                self._wait(s)
+                if s.event is not None:
+                    s.event.synchronize()
                 if int(s.host_any[0]) != 0:
                     # some rank's certificate failed: the same batch again as an OP_SEARCH_EXACT request (the followers
                     # do what they are told; they never look at a flag)
                     self._leader_enqueue(q[lo:lo + nq], k, True, s)
-                    self._wait(s)
+                    if s.event is not None:
+                        s.event.synchronize()
                     s.repeats += 1
                     self.repeats += 1
                 D[lo:lo + nq] = s.host_s.numpy()
