@@ -41,7 +41,6 @@ _MAX_TOKENS_PER_PASS = 131072
 _PAIRS_PER_CHUNK = 4096
 _FIRST_FRACTION = 4
 _MIN_FIRST_CHUNK = 256
-_PREBUILD_MIN_PAIRS = 512   # from this many pairs on, result objects are built on the worker thread during the GPU pass
 _new_reranked = fast_constructor(RerankedDocument)
 
 
@@ -107,14 +106,12 @@ class Reranker:
     def is_loaded(self) -> bool:
         return self._loaded
 
-    def _score_pairs(self, queries: list[str], docs: list[str], background=None):
+    def _score_pairs(self, queries: list[str], docs: list[str]) -> list[float]:
         """Sigmoid scores of (query, document) pairs.  Pairs go through in chunks: while the GPU scores one
         chunk (the C call releases the GIL) a worker thread tokenises AND packs the next, so the calling
         thread does nothing between two GPU passes but hand over three arrays — host tokenisation and the
         cross-encoder pass overlap instead of adding up.  The first chunk is a quarter of the batch: its
-        tokenisation is the only one the GPU has to wait for, and small passes use the GPU badly.
-        `background` (optional callable): run on the worker thread behind the last chunk's tokenisation — i.e. while
-        the GPU scores — and handed back as `(scores, background())`."""
+        tokenisation is the only one the GPU has to wait for, and small passes use the GPU badly."""
         max_len = min(int(self.settings.truncate_length), self._max_len)
         with_types = self.model.cfg.type_vocab > 1
         n = len(docs)
@@ -143,21 +140,18 @@ class Reranker:
 
         scores: list[float] = []
         if not bounds:
-            return scores if background is None else (scores, background())
+            return scores
         if self._tok_pool is None:
             self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rerank-tokenise")
         pending = self._tok_pool.submit(prepare, *bounds[0])
-        extra = None
         for i in range(len(bounds)):
             parts = pending.result()
             if i + 1 < len(bounds):
                 pending = self._tok_pool.submit(prepare, *bounds[i + 1])
-            elif background is not None:
-                extra = self._tok_pool.submit(background)   # the worker has nothing left to tokenise: the GPU pass covers this
             for ids, types, cu in parts:
                 probs = self.model.classify_packed(ids, types, cu, sigmoid=True)
                 scores.extend(probs[:, 0].tolist())
-        return scores if background is None else (scores, extra.result())
+        return scores
 
     @staticmethod
     def _ranked(documents: list[Document], scores: list[float], top_n: int | None, make=_new_reranked) -> list:
@@ -173,17 +167,6 @@ class Reranker:
             out.append(make(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category or "",
                             score=float(scores[i])))
         return out
-
-    @staticmethod
-    def _ranked_prebuilt(objs: list, scores: list[float], top_n: int | None) -> list:
-        """_ranked for result objects that already exist (built on the worker thread while the GPU scored): fill in the
-        scores, order them.  Same order rule: descending score, ties keep retrieval order (stable sort)."""
-        for o, sc in zip(objs, scores):
-            o.__dict__["score"] = float(sc)
-        order = sorted(range(len(objs)), key=scores.__getitem__, reverse=True)
-        if top_n is not None:
-            order = order[:top_n]
-        return [objs[i] for i in order]
 
     def rerank(self, query: str, documents: list[Document], top_n: int | None = None) -> list[RerankedDocument]:
         if not self._loaded or self.model is None or self.tokenizer is None:
@@ -260,19 +243,9 @@ class Reranker:
         flat_d = [d.content for docs in documents_batch for d in docs]
         make = result_factory or _new_reranked
         out, pos = [], 0
-        if len(flat_d) >= _PREBUILD_MIN_PAIRS and (top_n is None or 2 * top_n >= max(len(docs) for docs in documents_batch)):
-            # most of the batch's documents come back: their result objects are built on the worker thread WHILE the GPU
-            # scores (3200 objects at top-100 are 2-3 ms of a 20 ms batch on the calling thread otherwise); the scores
-            # are filled in afterwards
-            def prebuild() -> list[list]:
-                return [[make(doc_id=d.doc_id, title=d.title, content=d.content, category=d.category or "", score=0.0)
-                         for d in docs] for docs in documents_batch]
-
-            scores, built = self._score_pairs(flat_q, flat_d, background=prebuild)
-            for docs, objs in zip(documents_batch, built):
-                out.append(self._ranked_prebuilt(objs, scores[pos:pos + len(docs)], top_n) if docs else [])
-                pos += len(docs)
-            return out
+        # (Building the result objects on the tokeniser's worker thread while the GPU scores was tried in round 4 and taken
+        # out again: the worker holds the GIL when the pass returns and the calling thread waits out its switch interval —
+        # config C went 18.8 -> 19.6 ms per batch.)
         scores = self._score_pairs(flat_q, flat_d) if flat_d else []
         for docs in documents_batch:
             out.append(self._ranked(docs, scores[pos:pos + len(docs)], top_n, make) if docs else [])

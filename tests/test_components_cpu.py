@@ -54,53 +54,6 @@ def test_ranked_is_stable_and_top_n():
     assert [d.doc_id for d in Reranker._ranked(docs, [0.2, 0.9, 0.2, 0.5], 2)] == [1, 3]
 
 
-def test_big_rerank_batches_build_their_result_objects_beside_the_gpu_pass():
-    """From 512 pairs on, a batch that returns most of its documents has its result objects built on the tokeniser's
-    worker thread while the model scores, the scores filled in afterwards: same objects, same order (descending score,
-    ties in retrieval order), same top_n slice as the one-thread form (reference order rule: reranker.py:262-270)."""
-    import numpy as np
-
-    from rag_inference_pipeline_amd.model_source import HashTokenizer
-
-    class StubModel:  # score from the pair's token count, with many ties
-        class cfg:
-            type_vocab = 2
-
-        def classify_packed(self, ids, types, cu, sigmoid=True):
-            return (1.0 / (1 + (np.diff(cu) % 7).astype(np.float64))).astype(np.float32)[:, None]
-
-    rr = Reranker(PipelineSettings(reranker_model_name="synthetic:ms-marco-MiniLM-L-6-v2"))
-    rr.model, rr.tokenizer, rr._max_len, rr._loaded = StubModel(), HashTokenizer(30522), 512, True
-    rng = np.random.default_rng(0)
-    words = ["alpha", "beta", "gamma", "delta", "epsilon"]
-    queries = [" ".join(rng.choice(words, size=3)) for _ in range(8)]
-    docs = [[Document(doc_id=100 * qi + j, title=f"t{j}", content=" ".join(rng.choice(words, size=int(rng.integers(2, 20)))),
-                      category="c" if j % 2 else "") for j in range(80)] for qi in range(8)]   # 640 pairs
-    docs[3] = []
-    calls = {"n": 0}
-    orig = Reranker._ranked_prebuilt
-
-    def counted(objs, scores, top_n):
-        calls["n"] += 1
-        return orig(objs, scores, top_n)
-
-    Reranker._ranked_prebuilt = staticmethod(counted)
-    try:
-        all_docs = rr.rerank_batch(queries, docs)                # prebuilt path
-        top60 = rr.rerank_batch(queries, docs, top_n=60)         # prebuilt (most come back)
-        assert calls["n"] == 14
-        top5 = rr.rerank_batch(queries, docs, top_n=5)           # few come back: objects only for those, one thread
-        assert calls["n"] == 14
-    finally:
-        Reranker._ranked_prebuilt = staticmethod(orig)
-    for qi in range(8):
-        want = rr.rerank(queries[qi], docs[qi])                   # the single-query path: _ranked
-        assert [(d.doc_id, d.score, d.title, d.category) for d in all_docs[qi]] == [(d.doc_id, d.score, d.title, d.category) for d in want]
-        assert [(d.doc_id, d.score) for d in top60[qi]] == [(d.doc_id, d.score) for d in want[:60]]
-        assert [(d.doc_id, d.score) for d in top5[qi]] == [(d.doc_id, d.score) for d in want[:5]]
-    assert all_docs[3] == [] and type(all_docs[0][0]).__name__ == "RerankedDocument"
-
-
 def test_resolve_model_never_downloads_and_knows_presets():
     with pytest.raises(RuntimeError, match="never downloads"):
         resolve_model("BAAI/definitely-not-cached-model", "embedding")
