@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(64) void head_out_kernel(const float* x, const floa
 }  // namespace ragb
 
 #include "gemm_wl.hip.h"  // big-batch GEMM with both operands through LDS-DMA (uses the types and helpers above)
+#include "gemm_w6.hip.h"  // the default mode's big-batch GEMM on 128 x 192 tiles
 #include "bert_lnf.hip.h"  // small kernels of the query encoder's folded LayerNorms
 #include "gemm_wt.hip.h"  // the same over activations in MFMA-fragment order (RAG_GEMM_F16 big-batch path)
 #include "bert_tiled.hip.h"  // embedding, LayerNorm, attention, pooling over that layout

@@ -60,6 +60,7 @@ struct rag_bert {
     std::vector<float*> fold_s, fold_b;
     bool lnf_ok = false;          // the query-encoder form (<= 1024 tokens) is on: RAG_AMD_ENCODER_LN_FOLD=1
     bool lnf_built = false;       // the folded images exist
+    bool use_w6 = false;          // RAG_AMD_GEMM_W6=1: big-batch two-plane GEMMs on 128 x 192 tiles (measured slower: off)
     bool lnf_big = false;         // the big-batch form (> 1024 tokens, gemm_nt_wl_kernel) is on: the default, RAG_AMD_LN_FOLD=0 turns it off
     float* y1 = nullptr;              // [ws_tokens][H]: the second pre-LayerNorm row buffer (x is the first)
     float2 *ts_a = nullptr, *ts_b = nullptr;   // [ws_tokens][H / 32] block statistics of x / y1
@@ -170,7 +171,7 @@ int ensure_ws(rag_bert* h, long long tokens, long long nseq) {
         if (h->lnf_ok || h->lnf_big) {
             // block statistics: 32-column blocks for up to 1024 tokens (query encoder), 128-column blocks beyond
             const long long ts_rows = std::min<long long>(t, 1056);
-            const size_t ts_n = std::max<size_t>((size_t)ts_rows * (c.hidden / 32), (size_t)t * ((c.hidden + 127) / 128));
+            const size_t ts_n = std::max<size_t>((size_t)ts_rows * (c.hidden / 32), (size_t)t * ((c.hidden + 63) / 64));
             if (h->lnf_ok) RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->y1), (size_t)ts_rows * c.hidden * sizeof(float)));
             RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_a), ts_n * sizeof(float2)));
             RAGC_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->ts_b), ts_n * sizeof(float2)));
@@ -208,6 +209,7 @@ struct WRef {
     const _Float16* wxf;   // one fp16 plane, fragment order (RAG_GEMM_F16)
     uint32_t* range_flag;  // this pass's "outside fp16's range" word (pinned host memory the device writes)
     bool background;       // rag_bert_set_background: small-batch GEMMs in their 32-KiB-LDS form
+    bool w6 = false;       // big-batch two-plane GEMMs on 128 x 192 tiles (RAG_AMD_GEMM_W6=1)
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel (sizes above 64 KiB need it)
@@ -234,6 +236,25 @@ int launch_wl(const ragb::GemmWlParams& g, hipStream_t st) {
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
+
+// The default mode's big-batch GEMM (two fp16 planes per operand): 128 x 128 tiles; with `w6` (RAG_AMD_GEMM_W6=1 at
+// rag_bert_create) 128 x 192 tiles where 192 divides N.  The wider tile was built on the reading that the kernel is bound by
+// LDS-DMA instructions per MFMA (0.28 instead of 0.33 at the same two workgroups per CU) and measured 0-7 % SLOWER on every
+// shape (round 4, gpurun_out/r4o: 568 vs 531 us at N = 384, 1082 vs 1038 at N = 1536, 673 vs 671 at N = 1152) — the reading
+// was wrong, or 254 registers leave the scheduler nothing to work with.  Kept as an opt-in with its tests; off by default.
+int launch_wl2(const ragb::GemmWlParams& g, hipStream_t st, bool w6) {
+    if (w6 && g.N % 192 == 0) {
+        auto fn = &ragb::gemm_nt_w6_kernel;
+        int rc = ensure_lds(reinterpret_cast<const void*>(fn), ragb::W6Geom::LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fn, dim3(ragb::xcd_grid(g.M, g.N, 128, 192)), dim3(256), ragb::W6Geom::LDS, st, g);
+        RAGC_HIP_TRY(hipGetLastError());
+        return RAG_OK;
+    }
+    return launch_wl<2, 1, 3, false>(g, st);
+}
+// columns per block of the big-batch tile statistics a model of hidden size H gets (the kernel its N = H GEMMs run on)
+int lnf_big_blkw(int H, bool w6) { return w6 && H % 192 == 0 ? 64 : 128; }
 
 template <int AK, int NW, int NB, int KS, int NS, int OCC>
 int launch_wt(const ragb::GemmWtParams& g, hipStream_t st) {
@@ -311,7 +332,7 @@ int launch_gemm(const float* A, int lda, const WRef& Wr, int ldw, const float* b
     // scripts/exp/gemm_wl_bench.hip on the cross-encoder's shapes
     const bool wl_ok = M > 1024 && ldw == K && N % 32 == 0 && (lda % 4) == 0;
     if (wl_ok && Wr.wx2 && K % 16 == 0)   // fp32 results: two fp16 planes per operand, three products
-        return launch_wl<2, 1, 3, false>(ragb::GemmWlParams{A, Wr.wx2, bias, R, C, M, N, K, lda, ldr, ldc, act, Wr.range_flag}, st);
+        return launch_wl2(ragb::GemmWlParams{A, Wr.wx2, bias, R, C, M, N, K, lda, ldr, ldc, act, Wr.range_flag}, st, Wr.w6);
     if (wl_ok && Wr.wx && K % 16 == 0) {  // fp32 results, fp32 range: three bf16 planes, six products
         const ragb::GemmWlParams g{A, Wr.wx, bias, R, C, M, N, K, lda, ldr, ldc, act, nullptr};
         return N <= 512 ? launch_wl<0, 1, 3, true>(g, st) : launch_wl<0, 1, 3, false>(g, st);
@@ -466,7 +487,7 @@ int launch_wl_lnf_a(rag_bert* h, const float* Y, const float2* rs_in, const _Flo
     ragb::GemmWlParams g{Y, img, b2, nullptr, C, M, N, K, K, 0, N, act, range_flag};
     g.rs_in = rs_in;
     g.fold_s = s_vec;
-    return launch_wl<2, 1, 3, false>(g, st);
+    return launch_wl2(g, st, h->use_w6);
 }
 
 int launch_wl_lnf_b(rag_bert* h, const float* A, int K, const _Float16* img, const float* bias, const float* R_plain,
@@ -478,10 +499,11 @@ int launch_wl_lnf_b(rag_bert* h, const float* A, int K, const _Float16* img, con
     g.ln_g = ln_g;
     g.ln_b = ln_b;
     g.ts_out = ts_out;
-    int rc = launch_wl<2, 1, 3, false>(g, st);
+    int rc = launch_wl2(g, st, h->use_w6);
     if (rc) return rc;
-    // the rows' (mean, rstd) from their N / 128 tile statistics, for the kernels that read them next
-    ragb::lnf_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st>>>(ts_out, N / 128, 128.f, h->cfg.ln_eps, rs_out, M);
+    // the rows' (mean, rstd) from their tile statistics, for the kernels that read them next
+    const int bw = lnf_big_blkw(N, h->use_w6);
+    ragb::lnf_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st>>>(ts_out, N / bw, (float)bw, h->cfg.ln_eps, rs_out, M);
     RAGC_HIP_TRY(hipGetLastError());
     return RAG_OK;
 }
@@ -645,7 +667,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
         const float* g_prev = pending ? (lw - kPerLayer)[10] : nullptr;
         const float* b_prev = pending ? (lw - kPerLayer)[11] : nullptr;
         const size_t at = (size_t)4 * l;
-        const WRef wq{lw[0], h->wx2[at + 0], nullptr, nullptr, range_flag, h->background};
+        const WRef wq{lw[0], h->wx2[at + 0], nullptr, nullptr, range_flag, h->background, h->use_w6};
         const bool last_first_only = first_only_out && l == c.n_layers - 1 && nseq < T;
         if (pending)
             rc = launch_wl_lnf_a(h, h->x, h->rs_a, h->wfold[2 * l], h->fold_s[2 * l], h->fold_b[2 * l], h->qkv, T, 3 * H, H, ACT_NONE,
@@ -661,7 +683,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                 attention_mfma_kernel<64><<<fgrid, dim3(64), 0, st>>>(h->qkv, cu, h->ctx, H, heads, scale, 1);
             RAGC_HIP_TRY(hipGetLastError());
             if (pending) {
-                gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps, 128);
+                gather_rows_ln_kernel<<<dim3((nseq + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, g_prev, b_prev, cu, h->pooled, nseq, H, c.ln_eps, lnf_big_blkw(H, h->use_w6));
             } else {
                 const int total = nseq * H;
                 gather_rows_kernel<<<dim3((total + 255) / 256), dim3(256), 0, st>>>(h->x, cu, h->pooled, nseq, H);
@@ -696,7 +718,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
                              range_flag, st);
         if (rc) return rc;
         if (l == c.n_layers - 1) {   // the last LayerNorm, materialised once for the output stage
-            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y, T, H, c.ln_eps, 128);
+            ln_from_tiles_kernel<<<dim3((T + 3) / 4), dim3(256), 0, st>>>(h->x, h->ts_a, lw[10], lw[11], h->y, T, H, c.ln_eps, lnf_big_blkw(H, h->use_w6));
             RAGC_HIP_TRY(hipGetLastError());
             xfinal = h->y;
         }
@@ -709,7 +731,7 @@ int forward_locked(rag_bert* h, const int* ids, const int* types, const int* cu,
             const size_t at = (size_t)4 * l + i;
             const bool two_plane = !h->force_x6 && h->weights_fit_f16 && !h->wx2.empty();
             return WRef{lw[wsrc[i]], two_plane ? h->wx2[at] : nullptr, h->wx.empty() ? nullptr : h->wx[at],
-                        h->wxf.empty() ? nullptr : h->wxf[at], range_flag, h->background};
+                        h->wxf.empty() ? nullptr : h->wxf[at], range_flag, h->background, h->use_w6};
         };
         const bool last_first_only = first_only_out && l == c.n_layers - 1 && !h->valu_attention && nseq < T;
         if (tiled) {
@@ -1174,6 +1196,8 @@ extern "C" int rag_bert_create(const rag_bert_config* cfg, const void* const* we
     h->row_major_only = rm && *rm == '1';
     const char* eg = getenv("RAG_AMD_ENCODER_GRAPH");
     h->use_graphs = !(eg && *eg == '0');
+    const char* w6e = getenv("RAG_AMD_GEMM_W6");
+    h->use_w6 = w6e && *w6e == '1';
     const char* ta = getenv("RAG_AMD_TILED_ATTENTION_F32");
     h->tiled_attention_f32 = ta && *ta == '1';
     if (hipHostMalloc(reinterpret_cast<void**>(&h->range_pin), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {

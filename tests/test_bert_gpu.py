@@ -419,13 +419,15 @@ def test_layernorms_folded_into_their_consumers_match_the_separate_launches(gpu_
     plain.close()
 
 
-@pytest.mark.parametrize("arch", ["cross", "minilm", "bge"])
-def test_big_batch_layernorms_are_applied_by_their_consumers(gpu_required, monkeypatch, arch):
+@pytest.mark.parametrize("arch,w6", [("cross", "0"), ("minilm", "0"), ("bge", "0"), ("cross", "1"), ("bge", "1")])
+def test_big_batch_layernorms_are_applied_by_their_consumers(gpu_required, monkeypatch, arch, w6):
     """Default mode above 1024 tokens: the GEMM that writes a layer's pre-LayerNorm sum leaves per-row statistics of each
     128-column tile in its epilogue, the GEMMs that read it apply the LayerNorm there (gamma folded into the image) or
     recompute the residual from it — no LayerNorm pass over the activations except the encoder's last.  Same values as
     the separate passes (RAG_AMD_LN_FOLD=0) and as the oracle: logits through the first-token tail, all hidden states,
-    mean and first-token pooling; a ragged token count; LayerNorm parameters away from (1, 0)."""
+    mean and first-token pooling; a ragged token count; LayerNorm parameters away from (1, 0).  w6 = "1": the same on the
+    opt-in 128 x 192-tile GEMM (RAG_AMD_GEMM_W6=1: statistics per 64-column block), folded and plain."""
+    monkeypatch.setenv("RAG_AMD_GEMM_W6", w6)
     if arch == "cross":
         cfg = _small(BertConfig.ms_marco_minilm_l6())
     elif arch == "minilm":
