@@ -792,6 +792,8 @@ def main() -> None:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
+    if sharded is not None:
+        sharded.close()
     index.close()
     if dist is not None:
         dist.barrier()

@@ -235,6 +235,7 @@ class FAISSStore:
             logger.info("Unloading FAISS index")
             if self._sharded is not None:
                 self._sharded.shutdown()
+                self._sharded.close()   # the own RCCL communicator(s), once nothing is in flight
                 self._sharded = None
             dev = self._index.device if self._index is not None else 0
             if self._index is not None:
