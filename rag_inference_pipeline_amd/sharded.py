@@ -225,17 +225,20 @@ class ShardedFlatIndex:
                 logger.warning("rag_comm_unique_id failed: %s", lib.rag_last_error().decode("utf-8", "replace"))
             else:
                 ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
-        payload = torch.cat([ident, torch.tensor([ok], dtype=torch.uint8)]).to(self.device)
+        # every rank must be able to join BEFORE anyone enters ncclCommInitRank (which waits for all of them)
+        ready = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ready.item()) != 1:
+            logger.warning("sharded index on rank %d: RCCL cannot be bound on every rank; torch.distributed collectives "
+                           "stay on the data path", self.rank)
+            return None
+        payload = ident.to(self.device)
         dist.broadcast(payload, src=0, group=self.group)
-        payload = payload.cpu()
+        raw = (C.c_uint8 * 128).from_buffer_copy(bytes(payload.cpu().tolist()))
         handle = C.c_void_p()
-        if ok and int(payload[128]) == 1:
-            raw = (C.c_uint8 * 128).from_buffer_copy(bytes(payload[:128].tolist()))
-            if lib.rag_comm_create(raw, self.rank, self.world, self.device.index or 0, C.byref(handle)) != 0:
-                ok = 0
-                logger.warning("rag_comm_create failed: %s", lib.rag_last_error().decode("utf-8", "replace"))
-        else:
+        if lib.rag_comm_create(raw, self.rank, self.world, self.device.index or 0, C.byref(handle)) != 0:
             ok = 0
+            logger.warning("rag_comm_create failed: %s", lib.rag_last_error().decode("utf-8", "replace"))
         agreed = torch.tensor([ok], dtype=torch.int32, device=self.device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)
         if int(agreed.item()) == 1:
@@ -468,7 +471,11 @@ class ShardedFlatIndex:
         if self.rank != 0:
             raise RuntimeError("leader_call() is for rank 0")
         if self.world > 1:
-            with self._lock:
+            with self._cv:
+                # searches in flight still read their queries out of the message ring (on their own stream when requests
+                # travel on a separate one): a request that is not counted in `_inflight` waits until they have drained
+                while self._inflight:
+                    self._cv.wait()
                 self._request(int(op))
 
     def _leader_enqueue(self, q: np.ndarray, k: int, exact: bool, slot: _Slot | None) -> _Slot:
