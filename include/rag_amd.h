@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 5
+#define RAG_AMD_ABI_VERSION 6
 
 /* status codes */
 #define RAG_OK 0
@@ -257,10 +257,13 @@ int rag_merge_topk_packed_flagged_device(int32_t device, int32_t metric, int32_t
  * rag_ivf_* restates the reference's candidate set:
  *   1. coarse quantizer: the flat scan (rag_index machinery) over the nlist centroids, nprobe best per query under the
  *      quantizer's metric, ties by ascending list number;
- *   2. every (query, probed list) pair scans its list with the canonical dot product of the flat search;
- *   3. the query's nprobe per-list top-k lists are merged: (score, then ascending stored id).
+ *   2. per pass of <= 32 queries the probe table becomes a mask of queries per list; every list that at least one query
+ *      probes is read ONCE and multiplied with the pass's queries by the flat scan's MFMA loop (the flat search's
+ *      canonical summation order and score bits); a query keeps candidates only from the lists it probes;
+ *   3. the workgroups' per-query top-k lists are merged: (score, then ascending stored id).
  * faiss ranks equal scores by its heap's visiting order; here the rule is the flat search's.  With nprobe >= nlist the
- * result equals rag_index_search's bit for bit.  k <= 256.  Parity status: as the flat search (unpinned against faiss
+ * result equals rag_index_search's bit for bit.  d <= 1024, nlist <= 32768, k <= 2048 (k above what one pass selects
+ * — 112 at d = 768 — takes rounds, as in the flat search).  Parity status: as the flat search (unpinned against faiss
  * itself; held to oracle/flat.py:ivf_search). */
 typedef struct rag_ivf rag_ivf;
 int rag_ivf_create(int32_t d, int32_t metric, int32_t quantizer_metric, int32_t device, rag_ivf** out);
@@ -278,6 +281,10 @@ int64_t rag_ivf_nlist(const rag_ivf* h);
  * rag_index_search (-1 / -+FLT_MAX padding when fewer than k rows are reachable).  Host pointers; blocks. */
 int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k, int32_t nprobe, float* out_scores,
                    int64_t* out_ids);
+/* The same with device pointers, enqueued on `stream` (the caller's; NULL = the default stream) without a host
+ * round trip — the form the embedder's device hand-off uses (rag_index_search_device's contract). */
+int rag_ivf_search_device(rag_ivf* h, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                          float* out_scores_dev, int64_t* out_ids_dev, void* stream);
 
 /* ---- C1: the shard step's collectives on an own RCCL communicator (SURVEY §8a "C1", §8e) ------------------- */
 

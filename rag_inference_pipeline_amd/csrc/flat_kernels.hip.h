@@ -1399,6 +1399,29 @@ __global__ void row_sqnorm_kernel(const float* X, long long row_stride, int d, l
     out[row0 + i] = canonical_sqnorm(X + (row0 + i) * row_stride, d);
 }
 
+// The same per QUERY (a few rows, on the critical path of every L2 search): one wave per row stages it in LDS with
+// coalesced loads, then one lane runs the canonical chain from there (a thread per row waits for a dependent global
+// load every few terms: 17 us for d = 768; this is 4).  Same bits as row_sqnorm_kernel.
+__global__ __launch_bounds__(64) void query_sqnorm_kernel(const float* Q, int d, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float qrow[];
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int d8 = (d + 7) & ~7;
+    for (int c = lane; c < d8; c += 64) qrow[c] = c < d ? Q[(size_t)q * d + c] : 0.f;
+    __syncthreads();
+    if (lane == 0) {
+        float acc = 0.f;
+        for (int s = 0; s < d8; s += 8) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + s), b = *reinterpret_cast<const f32x4*>(qrow + s + 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc = __builtin_fmaf(a[t], a[t], acc);
+                acc = __builtin_fmaf(b[t], b[t], acc);
+            }
+        }
+        out[q] = acc;
+    }
+}
+
 __global__ void fill_neutral_kernel(float* scores, long long* ids, int total, int metric) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;

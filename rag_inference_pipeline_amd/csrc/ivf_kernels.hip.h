@@ -1,97 +1,478 @@
-// ivf_kernels.hip.h — list scan of the IVFFlat `nprobe` mode (rag_ivf_* in include/rag_amd.h).
+// ivf_kernels.hip.h — the IVFFlat `nprobe` mode (rag_ivf_* in include/rag_amd.h): plan + batch list scan.
 //
-// The reference's own data generator writes a faiss IndexIVFFlat (scripts/create_test_docs.py:83-104: nlist 4096,
-// nprobe 64) and FAISSStore.load sets `index.nprobe` (faiss_store.py:84-92): on such a file the reference does NOT
-// search exhaustively — a query only sees the rows of the `nprobe` inverted lists whose centroids are nearest to it.
-// This kernel is step 2 of that search (step 1, the coarse quantizer, is the flat scan over the nlist centroids):
-// one workgroup per (query, probed list) scores every row of the list with the canonical dot product of the flat
-// search (flat_kernels.hip.h; oracle/flat_oracle.c:rago_dot) and emits the list's best k ranking keys; the tournament
-// merge of the flat search then ranks the nprobe lists of a query.  Ranking is (score, ascending stored id) — faiss
-// leaves ties to its heap's visiting order; the candidate SET (the union of the probed lists) is what the mode is about.
+// The reference's own data generator writes a faiss IndexIVFFlat (scripts/create_test_docs.py:83-104: 4.5M x 768, L2,
+// nlist 4096, nprobe 64) and FAISSStore.load sets `index.nprobe` (faiss_store.py:84-92): on such a file the reference
+// does NOT search exhaustively — a query only sees the rows of the `nprobe` inverted lists whose centroids are nearest
+// to it.  Step 1, the coarse quantizer, is the flat scan over the nlist centroids.  Step 2 is here and is built the way
+// the flat scan is, because it is the same HBM-bound job on a subset of the rows:
+//
+//   * rows live in LIST order, every list padded to whole 32-row tiles (padding rows are zeros with id 0xFFFFFFFF), so a
+//     wave's tile never straddles two lists;
+//   * `ivf_plan_kernel` (one workgroup) turns a pass's probe table [nq <= 32][nprobe] into per-list query MASKS and a work
+//     list of items = up to 8 consecutive tiles of a list that at least one query probes.  A list probed by several
+//     queries of the batch is read ONCE;
+//   * `ivf_batch_scan_kernel` (one 8-wave workgroup per CU, items dealt by ticket): a wave multiplies its 32-row tile
+//     with ALL 32 queries of the pass on v_mfma_f32_32x32x2_f32 — the flat scan's inner loop, hence the flat search's
+//     canonical summation order and score bits — and lanes of queries that do not probe the item's list drop their
+//     scores.  The matrix pipe does up to 32x the needed products and does not care: the kernel moves 3 KB per row at
+//     HBM rate and the pipe runs at about half of its peak beside it, as in the flat scan.  Selection is the flat scan's
+//     (threshold filter -> LDS candidate buffers -> wave bitonic sort on overflow); a workgroup emits its best k keys per
+//     query and the flat search's tournament merge ranks the workgroups' lists.
+//
+// Ranking is (score, ascending stored id) — faiss leaves ties to its heap's visiting order; the candidate SET (the union
+// of the probed lists) is what the mode is about.  With nprobe >= nlist the result equals rag_index_search's bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace ragk {
 
-constexpr int kIvfMaxK = 256;   // keys a workgroup keeps per (query, list)
+constexpr uint32_t kIvfPadId = 0xFFFFFFFFu;   // id of a padding row
+constexpr int kIvfItemTiles = 8;                // tiles per work item = waves per workgroup
+constexpr int kIvfMaxLists = 32768;             // the plan kernel keeps one mask word per list in LDS
+constexpr int kIvfThrStride = 32;               // words between two queries' shared thresholds: a 128-byte line each
 
-struct IvfScanParams {
-    const float* X;            // [n][row_stride] rows in LIST order, columns zero-padded to d8
-    long long row_stride;
-    const float* xnorm;        // [n] canonical squared norms (L2), list order
-    const uint32_t* ids;       // [n] stored id of each list-order row
-    const long long* list_off; // [nlist + 1]
-    const float* Q;            // [nq][d]
-    const float* qnorm;        // [nq] (L2)
-    const long long* probe;    // [nq][nprobe] list numbers from the coarse search, -1 = none
-    u64* partial;              // [nq][nprobe][k] ranking keys, best first, 0 = empty
-    int d, d8, nprobe, k, l2;
+struct IvfItem {          // 16 bytes: one ticket's work
+    uint32_t first_tile;  // global tile number (rows 32 * first_tile ...)
+    uint32_t n_tiles;     // 1..8; 0 = no more items
+    uint32_t mask;        // bit q: query q of the pass probes this list
+    uint32_t list;
 };
 
-// 512 keys in LDS, descending, by 256 threads (bitonic network: 45 compare-exchange steps)
-__device__ __forceinline__ void ivf_sort512_desc(u64* keys, int t) {
-    for (int size = 2; size <= 512; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            const int lo = 2 * t - (t & (stride - 1));   // the pair (lo, lo + stride)
-            const bool desc = (lo & size) == 0;
-            const u64 a = keys[lo], b = keys[lo + stride];
-            if ((a < b) == desc) {
-                keys[lo] = b;
-                keys[lo + stride] = a;
-            }
-        }
+struct IvfPlanParams {
+    const long long* probe;     // [nq][nprobe] list numbers from the coarse search, -1 = none
+    const uint32_t* tile_off;   // [nlist + 1] first tile of each list (padded layout)
+    IvfItem* items;             // out: [<= n_tiles / 8 + nlist]
+    uint32_t* n_items;          // out
+    uint32_t* gthr;             // [kQT * kIvfThrStride] the scan's shared thresholds: zeroed here
+    int nq, nprobe, nlist;
+};
+
+// One workgroup of 1024 threads: masks in LDS, then lists 1024 at a time: items per list -> running prefix -> item records.
+__global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
+    uint32_t* mask = reinterpret_cast<uint32_t*>(ivf_smem);   // [nlist]
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t base_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int l = t; l < p.nlist; l += 1024) mask[l] = 0u;
+    if (t == 0) base_s = 0u;
+    if (t < kQT) p.gthr[t * kIvfThrStride] = 0u;
+    __syncthreads();
+    const int np = p.nq * p.nprobe;
+    for (int i = t; i < np; i += 1024) {
+        const long long l = p.probe[i];
+        if (l >= 0 && l < p.nlist) atomicOr(&mask[l], 1u << (i / p.nprobe));
     }
     __syncthreads();
+    for (int l0 = 0; l0 < p.nlist; l0 += 1024) {
+        const int l = l0 + t;
+        uint32_t m = 0u, ft = 0u, nt = 0u;
+        if (l < p.nlist) {
+            m = mask[l];
+            ft = p.tile_off[l];
+            nt = p.tile_off[l + 1] - ft;
+        }
+        const uint32_t ng = m ? (nt + kIvfItemTiles - 1) / kIvfItemTiles : 0u;
+        uint32_t incl = ng;   // inclusive prefix within the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const uint32_t at = before + incl - ng;
+        // the records of a list are written by the whole wave (the generator's Gaussian rows put 800 000 of 4.5M rows —
+        // 3000 items — into one list: written by the list's own thread that was 0.3 ms of a 2.9 ms search)
+        unsigned long long todo = __ballot(ng != 0u);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const uint32_t l_ft = __shfl(ft, src, 64), l_nt = __shfl(nt, src, 64), l_m = __shfl(m, src, 64);
+            const uint32_t l_ng = __shfl(ng, src, 64), l_at = __shfl(at, src, 64);
+            for (uint32_t j = lane; j < l_ng; j += 64) {
+                const uint32_t left = l_nt - j * kIvfItemTiles;
+                p.items[l_at + j] = IvfItem{l_ft + j * kIvfItemTiles, left < (uint32_t)kIvfItemTiles ? left : (uint32_t)kIvfItemTiles, l_m,
+                                            (uint32_t)(l0 + 64 * wave + src)};
+            }
+        }
+        __syncthreads();
+        if (t == 1023) base_s = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) *p.n_items = base_s;
 }
 
-__global__ __launch_bounds__(256) void ivf_list_scan_kernel(const IvfScanParams p) {
+struct IvfBatchParams {
+    const float* X;            // rows in padded list order, row_stride floats per row (columns zero-padded to d8)
+    long long row_stride;
+    const float* xnorm;        // [rows] canonical squared norms (L2)
+    const uint32_t* ids;       // [rows] stored id, kIvfPadId for padding rows
+    const float* Q;            // [nq][d]
+    const float* qnorm;        // [nq] (L2): a non-finite one means no results
+    const IvfItem* items;
+    const uint32_t* n_items;
+    uint32_t* ticket;          // 0 at launch; the last workgroup to leave zeroes it again
+    uint32_t* done;            // workgroups that have left (same)
+    u64* partial;              // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
+    const u64* ceil;           // [kQT] or null: only keys strictly below ceil[q] are candidates (k > max_k rounds)
+    uint32_t* gthr;            // [kQT * kIvfThrStride] thresholds shared by the workgroups (ord32 of a score, 0 = none
+                               // yet; one 128-byte line per query): see the filter
+    int d, d8, nq, k, l2;
+};
+
+// LDS: [Q fragments d8 * 128 B][keys 32 * C * 8 B][cnt 32][thr 32][flag 4][item records 2 x 4 words][sequence word + pad]
+__host__ __device__ inline size_t ivf_scan_lds_bytes(int d8, int C) {
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + 32 + 16;
+}
+
+// E = candidate buffer capacity / 64, D = register ring depth (steps of 32 bytes per row in flight per wave).
+template <int E, int D>
+__global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParams p) {
+    constexpr int NW = kIvfItemTiles;
+    constexpr int C = 64 * E;
     extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
-    u64* keys = reinterpret_cast<u64*>(ivf_smem);                 // [512]: best 256 | this chunk's 256
-    float* qv = reinterpret_cast<float*>(ivf_smem + 512 * 8);     // [d8]
-    const int t = threadIdx.x, slot = blockIdx.x, q = blockIdx.y;
-    u64* out = p.partial + ((size_t)q * p.nprobe + slot) * p.k;
-    const long long list = p.probe[(size_t)q * p.nprobe + slot];
-    const bool dead_query = p.l2 && !(p.qnorm[q] <= 3.402823466e+38f);   // every distance is inf or NaN: no results
-    if (list < 0 || dead_query) {   // workgroup-uniform
-        for (int i = t; i < p.k; i += 256) out[i] = 0ull;
-        return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int S = p.d8 >> 3;
+
+    f32x4* qf = reinterpret_cast<f32x4*>(ivf_smem);
+    u64* keys = reinterpret_cast<u64*>(ivf_smem + (size_t)S * 1024);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(keys + (size_t)kQT * C);
+    float* thr = reinterpret_cast<float*>(cnt + kQT);
+    uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
+    // the item of iteration it sits in itemw[4 (it & 1) ..]; itemw[8] = the newest iteration whose item is posted.
+    // Thread 0 writes record then number, readers read number then record (LDS operations of a wave execute in order)
+    volatile uint32_t* itemw = reinterpret_cast<volatile uint32_t*>(flag + 4);
+
+    // ---- the deal.  Item i of the work list: iteration 0 of workgroup b takes item b, iteration 1 item grid + b, every
+    // later one the item of a TICKET (item = ticket + 2 grid) drawn from one global counter.  Thread 0 runs a three-deep
+    // pipeline at the TOP of each iteration — post the record fetched an iteration ago (for iteration it + 1), fetch the
+    // record of the ticket drawn an iteration ago (it + 2), draw the next ticket (it + 3) — so every returning memory
+    // operation has a whole tile time before its result is used, and the use sits right behind the iteration's barrier,
+    // where the wave's load queue is drained anyway (vmcnt counts in order: a wait for the ticket in the middle of the
+    // K loop would be a wait for the whole register ring).
+    uint32_t n_items = 0u, g_pend = 0u;
+    IvfItem rec_pend{0u, 0u, 0u, 0u};
+    if (tid == 0) {
+        n_items = *p.n_items;
+        IvfItem rec0{0u, 0u, 0u, 0u};
+        if (blockIdx.x < n_items) rec0 = p.items[blockIdx.x];
+        if (gridDim.x + blockIdx.x < n_items) rec_pend = p.items[gridDim.x + blockIdx.x];
+        g_pend = atomicAdd(p.ticket, 1u);
+        itemw[0] = rec0.first_tile;
+        itemw[1] = rec0.n_tiles;
+        itemw[2] = rec0.mask;
+        itemw[8] = 0u;
     }
-    for (int c = t; c < p.d8; c += 256) qv[c] = c < p.d ? p.Q[(size_t)q * p.d + c] : 0.f;
-    keys[t] = 0ull;
-    const long long r0 = p.list_off[list], n = p.list_off[list + 1] - r0;
-    __syncthreads();
-    const int d4 = p.d8 >> 2;
-    const f32x4* q4 = reinterpret_cast<const f32x4*>(qv);
-    for (long long base = 0; base < n; base += 256) {
-        u64 key = 0ull;
-        const long long row = r0 + base + t;
-        if (base + t < n) {
-            // the canonical chain: groups of 8 visited 0,4,1,5,2,6,3,7, one fmaf per term, start +0
-            const f32x4* x4 = reinterpret_cast<const f32x4*>(p.X + row * p.row_stride);
-            float acc = 0.f;
-            f32x4 xa = x4[0], xb = x4[1];
-            for (int s = 2; s <= d4; s += 2) {   // the next group's row values are requested under this group's chain
-                const int sn = s < d4 ? s : 0;
-                const f32x4 xa_n = x4[sn], xb_n = x4[sn + 1];
-                const f32x4 qa = q4[s - 2], qb = q4[s - 1];
+
+    // ---- prologue: queries -> MFMA B fragments in LDS: fragment (s, l) = Q[l & 31][8 s + 4 (l >> 5) .. + 3]
+    {
+        constexpr int PU = 12;
+        const bool have_q = r < p.nq;
+        const float* qbase = p.Q + (size_t)(have_q ? r : 0) * p.d;
+        const bool q_vec = (p.d & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Q) & 15) == 0;
+        for (int s0 = wave; s0 < S; s0 += NW * PU) {
+            f32x4 v[PU];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc = __builtin_fmaf(xa[e], qa[e], acc);
-                    acc = __builtin_fmaf(xb[e], qb[e], acc);
+            for (int u = 0; u < PU; ++u) {
+                const int s = s0 + NW * u;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (s < S && have_q) {
+                    const int col = 8 * s + 4 * h;
+                    if (q_vec && col + 3 < p.d) {
+                        v[u] = *reinterpret_cast<const f32x4*>(qbase + col);
+                    } else {
+                        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                        if (col + 0 < p.d) t[0] = qbase[col + 0];
+                        if (col + 1 < p.d) t[1] = qbase[col + 1];
+                        if (col + 2 < p.d) t[2] = qbase[col + 2];
+                        if (col + 3 < p.d) t[3] = qbase[col + 3];
+                        v[u] = t;
+                    }
                 }
-                xa = xa_n;
-                xb = xb_n;
             }
-            float score = acc + 0.0f;
-            if (p.l2) score = __builtin_fmaf(2.0f, acc, -p.xnorm[row]) + 0.0f;
-            if (score >= RAGK_SCORE_FLOOR) key = make_key(score, p.ids[row]);   // NaN, -inf, -FLT_MAX: never a result
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int s = s0 + NW * u;
+                if (s < S) qf[s * 64 + lane] = v[u];
+            }
         }
-        keys[256 + t] = key;
-        ivf_sort512_desc(keys, t);   // the best 256 of (best so far, this chunk) are in front again
+        if (tid < kQT) {
+            float t0 = RAGK_SCORE_FLOOR;
+            // L2 with ||q||^2 = inf / NaN: every distance is inf or NaN, which faiss's heap never admits
+            if (tid < p.nq && p.l2 && !(p.qnorm[tid] <= 3.402823466e+38f)) t0 = __builtin_nanf("");
+            cnt[tid] = 0;
+            thr[tid] = tid < p.nq ? t0 : __builtin_inff();   // unused query columns parked
+        }
+        if (tid < 4) flag[tid] = 0;
     }
-    for (int i = t; i < p.k; i += 256) out[i] = keys[i];
+    __syncthreads();
+
+    const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
+    auto row_ptr = [&](uint32_t tile) -> const float* { return p.X + ((long long)tile * kTileRows + r) * p.row_stride + 4 * h; };
+
+    uint32_t first = itemw[0], ntl = itemw[1], imask = itemw[2];   // iteration 0's item (posted before the barrier)
+    f32x4 xb[D];
+    const float* pc = p.X;
+    bool active = (uint32_t)wave < ntl;
+    if (active) {
+        pc = row_ptr(first + wave);
+#pragma unroll
+        for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+    }
+
+    uint32_t seq = 0, g_seen = 0u;
+    for (int it = 0; ntl != 0u; ++it) {   // workgroup-uniform
+        if (tid == 0) {
+            volatile uint32_t* w = itemw + 4 * ((it + 1) & 1);
+            w[0] = rec_pend.first_tile;
+            w[1] = rec_pend.n_tiles;
+            w[2] = rec_pend.mask;
+            itemw[8] = (uint32_t)(it + 1);
+            const uint32_t idx = g_pend + 2u * gridDim.x;
+            IvfItem nx{0u, 0u, 0u, 0u};
+            if (idx < n_items) nx = p.items[idx];
+            rec_pend = nx;
+            g_pend = atomicAdd(p.ticket, 1u);
+        }
+        // Shared thresholds.  A workgroup meets a given query in one or two of its ~30 items (a query probes 64 of the
+        // batch's ~1600 lists), so a filter that learns only from the workgroup's own rows stays cold: every first meeting
+        // puts 256 rows into a 64-slot buffer — overflow, workgroup-wide sort, retry.  So a k-th best established in a sort
+        // is published (atomic max on the ordered score, one line per query) and wave 0 refreshes the local filters from the
+        // published values once per iteration — the load of one iteration is consumed at the top of the next, like the
+        // ticket.  k rows with at least the published score exist somewhere, hence a row below it is not in the query's
+        // top k; a stale value is only a weaker bound.
+        if (p.gthr && wave == 0 && lane < kQT) {
+            if (g_seen) {
+                const float tg = unord32(g_seen);
+                if (tg > thr[lane]) thr[lane] = tg;   // NaN (dead query) and +inf (unused column) filters stay
+            }
+            g_seen = __hip_atomic_load(p.gthr + lane * kIvfThrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const uint32_t tile = first + wave;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+        constexpr int G = D >= 4 ? 4 : D;
+        uint32_t first_n = 0u, ntl_n = 0u, imask_n = 0u;
+        auto read_next = [&]() {
+            while (itemw[8] != (uint32_t)(it + 1)) {
+            }
+            volatile uint32_t* w = itemw + 4 * ((it + 1) & 1);
+            first_n = __builtin_amdgcn_readfirstlane(w[0]);
+            ntl_n = __builtin_amdgcn_readfirstlane(w[1]);
+            imask_n = __builtin_amdgcn_readfirstlane(w[2]);
+        };
+        if (active) {   // wave-uniform
+            f32x4 qcur = qf[lane];
+            int s0 = 0;
+            for (; s0 < S - D; s0 += D) {
+                const float* src = pc + 8 * (s0 + D);
+                const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < D; g += G) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const int i = g + j;
+                        const f32x4 qn = qs[i * 64];
+                        acc = scan_step<0>(xb[i], qcur, acc);
+                        qcur = qn;
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(src + 8 * (g + j));
+                    __builtin_amdgcn_sched_group_barrier(0x020, G, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            read_next();
+            // last D steps: the ring refills from this wave's tile of the next item (or once more from this one's start)
+            const float* pn = (uint32_t)wave < ntl_n ? row_ptr(first_n + wave) : pc;
+            {
+                const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
+#pragma unroll
+                for (int g = 0; g < D; g += G) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j) {
+                        const int i = g + j;
+                        const f32x4 qn = qs[(i + 1 < D ? i : -1 - s0) * 64];
+                        acc = scan_step<0>(xb[i], qcur, acc);
+                        qcur = qn;
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < G; ++j) xb[g + j] = *reinterpret_cast<const f32x4*>(pn + 8 * (g + j));
+                    __builtin_amdgcn_sched_group_barrier(0x020, G, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            pc = pn;
+        } else {
+            read_next();
+            if ((uint32_t)wave < ntl_n) {
+                pc = row_ptr(first_n + wave);
+#pragma unroll
+                for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
+            }
+        }
+
+        // ---- ranking scores.  Lane (r, h): query r, tile rows (i & 3) + 8 (i >> 2) + 4 h
+        const long long row0 = (long long)tile * kTileRows;
+        float sc[16];
+        if (p.l2) {   // kernel-uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+                if (active) xn = *reinterpret_cast<const f32x4*>(p.xnorm + row0 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[4 * g + j] = __builtin_fmaf(2.0f, acc[4 * g + j], -xn[j]) + 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[i] = acc[i] + 0.0f;
+        }
+
+        // ---- filter + append: only the queries that probe this item's list
+        const bool mine = active && ((imask >> r) & 1u);
+        uint32_t pending = 0;
+        if (mine) {
+            const float t = thr[r];
+            float m = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) m = fmaxf(m, sc[i]);
+            if (m >= t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (sc[i] >= t) {
+                        const uint32_t id = p.ids[row0 + (i & 3) + 8 * (i >> 2) + 4 * h];
+                        const u64 key = make_key(sc[i], id);
+                        if (id != kIvfPadId && key < key_ceil) {
+                            const uint32_t slot = atomicAdd(&cnt[r], 1u);
+                            if (slot < (uint32_t)C) {
+                                keys[(size_t)r * C + slot] = key;
+                            } else {
+                                pending |= 1u << i;
+                                flag[seq & 3] = 1;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- overflow handling: synchronised compaction of every query, then retry (flat_kernels.hip.h)
+        for (;;) {
+            __syncthreads();
+            const bool need = flag[seq & 3] != 0;
+            if (tid == 0) flag[(seq + 2) & 3] = 0;
+            ++seq;
+            if (!need) break;
+            {
+                constexpr int NQW = kQT / NW;
+                u64 kk[NQW][E];
+                uint32_t nn[NQW];
+#pragma unroll
+                for (int j = 0; j < NQW; ++j) {
+                    const int q = wave + NW * j;
+                    nn[j] = min(cnt[q], (uint32_t)C);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const uint32_t idx = e * 64 + lane;
+                        kk[j][e] = idx < nn[j] ? keys[(size_t)q * C + idx] : 0ull;
+                    }
+                }
+                wave_sort_desc<E, NQW>(kk, lane);
+#pragma unroll
+                for (int j = 0; j < NQW; ++j) {
+                    const int q = wave + NW * j;
+                    if (nn[j] > 0) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int idx = e * 64 + lane;
+                            if (idx < p.k) keys[(size_t)q * C + idx] = kk[j][e];
+                            if (idx == p.k - 1 && nn[j] >= (uint32_t)p.k) {
+                                const float kth = unord32((uint32_t)(kk[j][e] >> 32));
+                                if (kth > thr[q]) {   // (a refreshed filter may already be above this workgroup's k-th best)
+                                    thr[q] = kth;
+                                    if (p.gthr) atomicMax(p.gthr + q * kIvfThrStride, (uint32_t)(kk[j][e] >> 32));
+                                }
+                            }
+                        }
+                        if (lane == 0) cnt[q] = min(nn[j], (uint32_t)p.k);
+                    }
+                }
+            }
+            __syncthreads();
+            if (pending) {
+                const float t = thr[r];
+                uint32_t still = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if ((pending >> i) & 1u) {
+                        if (sc[i] >= t) {
+                            const uint32_t id = p.ids[row0 + (i & 3) + 8 * (i >> 2) + 4 * h];
+                            const uint32_t slot = atomicAdd(&cnt[r], 1u);
+                            if (slot < (uint32_t)C) {
+                                keys[(size_t)r * C + slot] = make_key(sc[i], id);
+                            } else {
+                                still |= 1u << i;
+                                flag[seq & 3] = 1;
+                            }
+                        }
+                    }
+                }
+                pending = still;
+            }
+        }
+        first = first_n;
+        ntl = ntl_n;
+        imask = imask_n;
+        active = (uint32_t)wave < ntl;
+    }
+
+    // ---- epilogue: sort every buffer, emit k keys per query for this workgroup
+    {
+        constexpr int NQW = kQT / NW;
+        u64 kk[NQW][E];
+#pragma unroll
+        for (int j = 0; j < NQW; ++j) {
+            const int q = wave + NW * j;
+            const uint32_t n = min(cnt[q], (uint32_t)C);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t idx = e * 64 + lane;
+                kk[j][e] = idx < n ? keys[(size_t)q * C + idx] : 0ull;
+            }
+        }
+        wave_sort_desc<E, NQW>(kk, lane);
+#pragma unroll
+        for (int j = 0; j < NQW; ++j) {
+            const int q = wave + NW * j;
+            u64* out = p.partial + ((size_t)q * gridDim.x + blockIdx.x) * p.k;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int idx = e * 64 + lane;
+                if (idx < p.k) out[idx] = kk[j][e];
+            }
+        }
+    }
+    // the last workgroup to leave puts the ticket counter back (launches of an index are stream-ordered)
+    __syncthreads();
+    if (tid == 0) {
+        if (atomicAdd(p.done, 1u) == gridDim.x - 1) {
+            *p.ticket = 0u;
+            *p.done = 0u;
+        }
+    }
 }
 
 }  // namespace ragk

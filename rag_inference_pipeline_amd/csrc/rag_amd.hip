@@ -446,7 +446,11 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
     const bool l2 = h->metric == RAG_METRIC_L2;
     const long long n_tiles_ll = (h->n + kTileRows - 1) / kTileRows;
     const int n_tiles = (int)n_tiles_ll;
-    int grid = (int)std::min<long long>(h->n_cus, (n_tiles_ll + waves - 1) / waves);
+    // a corpus of fewer tiles than the chip has wave slots is spread over ALL CUs (the tile walk's partial round deals one
+    // tile per workgroup before any gets two) instead of filling ceil(n_tiles / 8) of them: the IVF mode's coarse
+    // quantizer — 4096 centroids, k = nprobe = 64 — ran as 16 workgroups of 256 rows each, three overflow sorts per query
+    // (84 us); as 128 workgroups of one tile nothing overflows
+    int grid = (int)std::min<long long>(h->n_cus, n_tiles_ll);
     grid = std::max(grid, 1);
     const int n_iters = (n_tiles + grid * waves - 1) / (grid * waves);
 
@@ -460,7 +464,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
     }
 
     if (l2) {
-        row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(q_dev, h->d, h->d, 0, nq, h->qnorm);
+        query_sqnorm_kernel<<<dim3(nq), dim3(64), (size_t)h->d8 * sizeof(float), st>>>(q_dev, h->d, h->qnorm);
         HIP_TRY(hipGetLastError());
     }
 
@@ -618,7 +622,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     int rc = ensure_search_ws(h, nb, kp, grid);
     if (rc) return rc;
     if (l2) {
-        row_sqnorm_kernel<<<dim3(1), dim3(64), 0, st>>>(qp, h->d, h->d, 0, nb, h->qnorm);
+        query_sqnorm_kernel<<<dim3(nb), dim3(64), (size_t)h->d8 * sizeof(float), st>>>(qp, h->d, h->qnorm);
         HIP_TRY(hipGetLastError());
     }
     // one id per two-stage search: the per-search flag words are "set" when they hold it (never 0)

@@ -4,20 +4,24 @@
 #include "ivf_kernels.hip.h"
 
 struct rag_ivf {
-    int device = 0, d = 0, d8 = 0, metric = 0;
+    int device = 0, d = 0, d8 = 0, metric = 0, n_cus = 0;
     long long n = 0, nlist = 0;
+    long long rows_padded = 0;        // every list rounded up to whole 32-row tiles
     rag_index* coarse = nullptr;      // flat index over the nlist centroids (the coarse quantizer)
-    float* X = nullptr;               // rows in list order, d8 columns
+    float* X = nullptr;               // rows in padded list order, d8 columns
     float* xnorm = nullptr;           // L2
-    uint32_t* ids = nullptr;
-    long long* list_off = nullptr;    // nlist + 1
-    hipStream_t stream = nullptr;
+    uint32_t* ids = nullptr;          // kIvfPadId on padding rows
+    uint32_t* tile_off = nullptr;     // nlist + 1: first tile of each list
+    hipStream_t stream = nullptr;     // the host-pointer entry point's stream
     std::mutex mu;
     // per-search workspace
     float* q_dev = nullptr; size_t q_cap = 0;
     float* qnorm = nullptr; size_t qn_cap = 0;
     float* c_scores = nullptr; long long* probe = nullptr; size_t probe_cap = 0;
+    ragk::IvfItem* items = nullptr; size_t items_cap = 0;
+    uint32_t* words = nullptr;        // [0] n_items, [1] ticket, [2] done (the scan kernel leaves [1], [2] at 0), [4 ...] shared thresholds (a line per query)
     ragk::u64* partial = nullptr; size_t partial_cap = 0;
+    ragk::u64* round_keys = nullptr;  // 2 x kQT keys (k > max_k rounds)
     float* out_s = nullptr; long long* out_i = nullptr; size_t out_cap = 0;
 };
 
@@ -38,7 +42,7 @@ int ivf_grow(T** p, size_t* cap, size_t want) {
 extern "C" int rag_ivf_create(int32_t d, int32_t metric, int32_t quantizer_metric, int32_t device, rag_ivf** out) {
     if (!out) return fail(RAG_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
-    if (d <= 0 || d > 4096) return fail(RAG_ERR_INVALID_ARG, "dimension %d out of range (IVF mode takes d <= 4096)", d);
+    if (d <= 0 || d > 1024) return fail(RAG_ERR_INVALID_ARG, "dimension %d out of range (the nprobe mode takes d <= 1024)", d);
     if ((metric != RAG_METRIC_INNER_PRODUCT && metric != RAG_METRIC_L2) ||
         (quantizer_metric != RAG_METRIC_INNER_PRODUCT && quantizer_metric != RAG_METRIC_L2))
         return fail(RAG_ERR_INVALID_ARG, "unknown metric");
@@ -55,6 +59,7 @@ extern "C" int rag_ivf_create(int32_t d, int32_t metric, int32_t quantizer_metri
     h->d8 = round_up(d, 8);
     h->metric = metric;
     h->coarse = coarse;
+    h->n_cus = coarse->n_cus;
     DeviceGuard g(device);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         rag_index_destroy(coarse);
@@ -71,7 +76,8 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         DeviceGuard g(h->device);
         std::lock_guard<std::mutex> lk(h->mu);
         (void)hipDeviceSynchronize();
-        void* ptrs[] = {h->X, h->xnorm, h->ids, h->list_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->partial, h->out_s, h->out_i};
+        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->items, h->words, h->partial,
+                        h->round_keys, h->out_s, h->out_i};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -86,8 +92,10 @@ extern "C" int64_t rag_ivf_nlist(const rag_ivf* h) { return h ? h->nlist : 0; }
 
 extern "C" int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_t nlist, const float* rows_host,
                                  const int64_t* ids_host, const int64_t* list_offsets_host) {
+    using namespace ragk;
     if (!h || nlist <= 0 || !centroids_host || !list_offsets_host) return fail(RAG_ERR_INVALID_ARG, "bad arguments");
     if (h->n || h->nlist) return fail(RAG_ERR_STATE, "the lists of this index are already set");
+    if (nlist > kIvfMaxLists) return fail(RAG_ERR_UNSUPPORTED, "the nprobe mode takes up to %d lists (nlist = %lld)", kIvfMaxLists, (long long)nlist);
     const long long n = list_offsets_host[nlist];
     if (list_offsets_host[0] != 0 || n < 0 || n > 0xFFFFFFFEll) return fail(RAG_ERR_INVALID_ARG, "list offsets must start at 0 and end below 2^32-1");
     for (int64_t l = 0; l < nlist; ++l)
@@ -97,79 +105,176 @@ extern "C" int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_
         if (ids_host[i] < 0 || ids_host[i] > 0xFFFFFFFEll) return fail(RAG_ERR_UNSUPPORTED, "stored id %lld outside [0, 2^32-2]", (long long)ids_host[i]);
     int rc = rag_index_add(h->coarse, centroids_host, nlist);
     if (rc) return rc;
-    DeviceGuard g(h->device);
-    std::lock_guard<std::mutex> lk(h->mu);
-    if ((rc = dev_alloc(&h->list_off, (size_t)nlist + 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(h->list_off, list_offsets_host, ((size_t)nlist + 1) * sizeof(long long), hipMemcpyHostToDevice, h->stream));
-    if (n > 0) {
-        if ((rc = dev_alloc(&h->X, (size_t)n * h->d8))) return rc;
-        if ((rc = dev_alloc(&h->ids, (size_t)n))) return rc;
-        if (h->d8 != h->d) HIP_TRY(hipMemsetAsync(h->X, 0, (size_t)n * h->d8 * sizeof(float), h->stream));
-        HIP_TRY(hipMemcpy2DAsync(h->X, (size_t)h->d8 * sizeof(float), rows_host, (size_t)h->d * sizeof(float),
-                                 (size_t)h->d * sizeof(float), (size_t)n, hipMemcpyHostToDevice, h->stream));
-        std::vector<uint32_t> ids32((size_t)n);
-        for (long long i = 0; i < n; ++i) ids32[(size_t)i] = (uint32_t)ids_host[i];
-        HIP_TRY(hipMemcpyAsync(h->ids, ids32.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));   // ids32 leaves scope
-        if (h->metric == RAG_METRIC_L2) {
-            if ((rc = dev_alloc(&h->xnorm, (size_t)n))) return rc;
-            ragk::row_sqnorm_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream>>>(h->X, h->d8, h->d, 0, n, h->xnorm);
-            HIP_TRY(hipGetLastError());
-        }
+    // padded layout: list l starts at tile tile_off[l]
+    std::vector<uint32_t> toff((size_t)nlist + 1);
+    long long tiles = 0;
+    for (int64_t l = 0; l < nlist; ++l) {
+        toff[(size_t)l] = (uint32_t)tiles;
+        tiles += (list_offsets_host[l + 1] - list_offsets_host[l] + kTileRows - 1) / kTileRows;
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->n = n;
-    h->nlist = nlist;
-    return RAG_OK;
-}
-
-extern "C" int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k, int32_t nprobe,
-                              float* out_scores, int64_t* out_ids) {
-    using namespace ragk;
-    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
-    if (nq < 0 || k <= 0 || nprobe <= 0) return fail(RAG_ERR_INVALID_ARG, "nq=%d k=%d nprobe=%d out of range", nq, k, nprobe);
-    if (nq > 0 && (!queries_host || !out_scores || !out_ids)) return fail(RAG_ERR_INVALID_ARG, "null query or output buffer");
-    if (nq == 0) return RAG_OK;
-    if (h->nlist == 0) return fail(RAG_ERR_STATE, "rag_ivf_set_lists has not been called");
-    if (k > kIvfMaxK) return fail(RAG_ERR_UNSUPPORTED, "the IVF mode returns up to %d results per query (k = %d)", kIvfMaxK, k);
-    const int np = (int)std::min<long long>(nprobe, h->nlist);
-    if (np > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "nprobe %d exceeds the merge kernel's %d lists", np, 256 * kMergeMaxOwned);
-    if (nq > 65535) return fail(RAG_ERR_UNSUPPORTED, "more than 65535 queries per call");
+    toff[(size_t)nlist] = (uint32_t)tiles;
+    const long long rows_padded = tiles * kTileRows;
+    if (rows_padded > 0xFFFFFFFFll) return fail(RAG_ERR_UNSUPPORTED, "too many rows");
     DeviceGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t st = h->stream;
+    if ((rc = dev_alloc(&h->tile_off, (size_t)nlist + 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->tile_off, toff.data(), ((size_t)nlist + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = dev_alloc(&h->words, (size_t)32 + ragk::kQT * ragk::kIvfThrStride))) return rc;
+    HIP_TRY(hipMemsetAsync(h->words, 0, (32 + ragk::kQT * ragk::kIvfThrStride) * sizeof(uint32_t), st));
+    if (rows_padded > 0) {
+        if ((rc = dev_alloc(&h->X, (size_t)rows_padded * h->d8))) return rc;
+        if ((rc = dev_alloc(&h->ids, (size_t)rows_padded))) return rc;
+        HIP_TRY(hipMemsetAsync(h->X, 0, (size_t)rows_padded * h->d8 * sizeof(float), st));
+        std::vector<uint32_t> ids32((size_t)rows_padded, kIvfPadId);
+        for (int64_t l = 0; l < nlist; ++l) {
+            const long long r0 = list_offsets_host[l], len = list_offsets_host[l + 1] - r0;
+            if (len == 0) continue;
+            const long long dst = (long long)toff[(size_t)l] * kTileRows;
+            for (long long i = 0; i < len; ++i) ids32[(size_t)(dst + i)] = (uint32_t)ids_host[r0 + i];
+            HIP_TRY(hipMemcpy2DAsync(h->X + dst * h->d8, (size_t)h->d8 * sizeof(float), rows_host + r0 * h->d, (size_t)h->d * sizeof(float),
+                                     (size_t)h->d * sizeof(float), (size_t)len, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(hipMemcpyAsync(h->ids, ids32.data(), (size_t)rows_padded * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));   // ids32 leaves scope
+        if (h->metric == RAG_METRIC_L2) {
+            if ((rc = dev_alloc(&h->xnorm, (size_t)rows_padded))) return rc;
+            row_sqnorm_kernel<<<dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, st>>>(h->X, h->d8, h->d, 0, rows_padded, h->xnorm);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    h->n = n;
+    h->nlist = nlist;
+    h->rows_padded = rows_padded;
+    return RAG_OK;
+}
+
+namespace {
+using IvfScanFn = void (*)(const ragk::IvfBatchParams);
+template <int E>
+IvfScanFn ivf_scan_fn_ring(int ring) {
+    switch (ring) {
+        case 8: return (IvfScanFn)ragk::ivf_batch_scan_kernel<E, 8>;
+        case 4: return (IvfScanFn)ragk::ivf_batch_scan_kernel<E, 4>;
+        default: return (IvfScanFn)ragk::ivf_batch_scan_kernel<E, 1>;
+    }
+}
+IvfScanFn ivf_scan_fn(int cap, int ring) {
+    switch (cap) {
+        case 64: return ivf_scan_fn_ring<1>(ring);
+        case 128: return ivf_scan_fn_ring<2>(ring);
+        default: return ivf_scan_fn_ring<4>(ring);
+    }
+}
+// candidate buffer capacity for k (a buffer must hold k and the next arrival), 0 = k needs rounds
+int ivf_capacity(int d8, int k) {
+    for (int c : {64, 128, 256})
+        if (k <= c - 16 && ragk::ivf_scan_lds_bytes(d8, c) <= 160 * 1024) return c;
+    return 0;
+}
+int ivf_max_k(int d8) {
+    int best = 0;
+    for (int c : {64, 128, 256})
+        if (ragk::ivf_scan_lds_bytes(d8, c) <= 160 * 1024) best = c - 16;
+    return best;
+}
+
+// the whole search on `st`, device pointers
+int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe, float* out_s, long long* out_i, hipStream_t st) {
+    using namespace ragk;
+    const int np = (int)std::min<long long>(nprobe, h->nlist);
+    const int kmax = ivf_max_k(h->d8);
+    const int grid = std::max(1, h->n_cus);
+    if (grid > 256 * kMergeMaxOwned) return fail(RAG_ERR_UNSUPPORTED, "scan grid %d too large for the merge kernel", grid);
     int rc;
-    if ((rc = ivf_grow(&h->q_dev, &h->q_cap, (size_t)nq * h->d))) return rc;
     if ((rc = ivf_grow(&h->qnorm, &h->qn_cap, (size_t)nq))) return rc;
     {
         size_t cap2 = h->probe_cap;
         if ((rc = ivf_grow(&h->c_scores, &cap2, (size_t)nq * np))) return rc;
         if ((rc = ivf_grow(&h->probe, &h->probe_cap, (size_t)nq * np))) return rc;
     }
-    if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)nq * np * k))) return rc;
+    if ((rc = ivf_grow(&h->items, &h->items_cap, (size_t)(h->rows_padded / kTileRows / kIvfItemTiles + h->nlist + 1)))) return rc;
+    if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)kQT * grid * std::min(k, kmax)))) return rc;
+    if (k > kmax && !h->round_keys && (rc = dev_alloc(&h->round_keys, (size_t)2 * kQT))) return rc;
+    // step 1: the coarse quantizer — the flat search over the centroids, nprobe nearest per query
+    rc = rag_index_search_device(h->coarse, q_dev, nq, np, h->c_scores, reinterpret_cast<int64_t*>(h->probe), (void*)st);
+    if (rc) return rc;
+    const bool l2 = h->metric == RAG_METRIC_L2;
+    if (l2) {
+        query_sqnorm_kernel<<<dim3(nq), dim3(64), (size_t)h->d8 * sizeof(float), st>>>(q_dev, h->d, h->qnorm);
+        HIP_TRY(hipGetLastError());
+    }
+    const bool share_thr = env_int("RAG_AMD_IVF_SHARED_THRESHOLDS", 1) != 0;   // (experiment switch; results do not depend on it)
+    const int S = h->d8 / 8;
+    const int ring = S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 1);
+    for (int b0 = 0; b0 < nq; b0 += kQT) {
+        const int nb = std::min(kQT, nq - b0);
+        // step 2: this pass's probe table -> list masks -> work items
+        IvfPlanParams pp{h->probe + (size_t)b0 * np, h->tile_off, h->items, h->words, h->words + 32, nb, np, (int)h->nlist};
+        ivf_plan_kernel<<<dim3(1), dim3(1024), (size_t)h->nlist * sizeof(uint32_t), st>>>(pp);
+        HIP_TRY(hipGetLastError());
+        // step 3: the probed lists, each read once, against the pass's queries; step 4: merge of the workgroups' lists
+        int done = 0, flip = 0;
+        while (done < k) {
+            const int kr = std::min(kmax, k - done);
+            const int cap = ivf_capacity(h->d8, kr);
+            const u64* ceil = done ? h->round_keys + (size_t)flip * kQT : nullptr;
+            u64* last = k > kmax ? h->round_keys + (size_t)(flip ^ 1) * kQT : nullptr;
+            IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_dev + (size_t)b0 * h->d, h->qnorm + b0, h->items, h->words, h->words + 1,
+                              h->words + 2, h->partial, ceil, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr, l2 ? 1 : 0};
+            if (done) HIP_TRY(hipMemsetAsync(h->words + 32, 0, kQT * kIvfThrStride * sizeof(uint32_t), st));   // a round's thresholds bind that round's candidates only
+            IvfScanFn fn = ivf_scan_fn(cap, ring);
+            const size_t lds = ivf_scan_lds_bytes(h->d8, cap);
+            if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
+            HIP_TRY(hipGetLastError());
+            KeyListSrc src{h->partial, grid, kr};
+            MergeOut mo{out_s + (size_t)b0 * k + done, out_i + (size_t)b0 * k + done, last, k, h->qnorm + b0, 0, h->metric, 0, nullptr, 0};
+            launch_merge(src, grid, nb, kr, merge_look(grid, kr, kr), mo, st);
+            HIP_TRY(hipGetLastError());
+            done += kr;
+            flip ^= 1;
+        }
+    }
+    return RAG_OK;
+}
+
+int ivf_check_args(rag_ivf* h, const void* q, int nq, int k, int nprobe, const void* os, const void* oi) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    if (nq < 0 || k <= 0 || nprobe <= 0) return fail(RAG_ERR_INVALID_ARG, "nq=%d k=%d nprobe=%d out of range", nq, k, nprobe);
+    if (nq > 0 && (!q || !os || !oi)) return fail(RAG_ERR_INVALID_ARG, "null query or output buffer");
+    if (nq > 0 && h->nlist == 0) return fail(RAG_ERR_STATE, "rag_ivf_set_lists has not been called");
+    if (nq > 65535) return fail(RAG_ERR_UNSUPPORTED, "more than 65535 queries per call");
+    if (k > 2048) return fail(RAG_ERR_UNSUPPORTED, "k = %d: the nprobe mode returns up to 2048 results per query", k);
+    return RAG_OK;
+}
+}  // namespace
+
+extern "C" int rag_ivf_search_device(rag_ivf* h, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                                     float* out_scores_dev, int64_t* out_ids_dev, void* stream) {
+    int rc = ivf_check_args(h, queries_dev, nq, k, nprobe, out_scores_dev, out_ids_dev);
+    if (rc || nq == 0) return rc;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    return ivf_search_locked(h, queries_dev, nq, k, nprobe, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), (hipStream_t)stream);
+}
+
+extern "C" int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k, int32_t nprobe,
+                              float* out_scores, int64_t* out_ids) {
+    int rc = ivf_check_args(h, queries_host, nq, k, nprobe, out_scores, out_ids);
+    if (rc || nq == 0) return rc;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipStream_t st = h->stream;
+    if ((rc = ivf_grow(&h->q_dev, &h->q_cap, (size_t)nq * h->d))) return rc;
     {
         size_t cap2 = h->out_cap;
         if ((rc = ivf_grow(&h->out_s, &cap2, (size_t)nq * k))) return rc;
         if ((rc = ivf_grow(&h->out_i, &h->out_cap, (size_t)nq * k))) return rc;
     }
     HIP_TRY(hipMemcpyAsync(h->q_dev, queries_host, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, st));
-    // step 1: the coarse quantizer — the flat search over the centroids, nprobe nearest per query
-    rc = rag_index_search_device(h->coarse, h->q_dev, nq, np, h->c_scores, reinterpret_cast<int64_t*>(h->probe), (void*)st);
-    if (rc) return rc;
-    if (h->metric == RAG_METRIC_L2) {
-        row_sqnorm_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st>>>(h->q_dev, h->d, h->d, 0, nq, h->qnorm);
-        HIP_TRY(hipGetLastError());
-    }
-    // step 2: every (query, probed list) pair scans its list; step 3: the merge of a query's nprobe lists
-    IvfScanParams sp{h->X, h->d8, h->xnorm, h->ids, h->list_off, h->q_dev, h->qnorm, h->probe, h->partial,
-                     h->d, h->d8, np, k, h->metric == RAG_METRIC_L2 ? 1 : 0};
-    const size_t lds = 512 * 8 + (size_t)h->d8 * sizeof(float);
-    ivf_list_scan_kernel<<<dim3((unsigned)np, (unsigned)nq), dim3(256), lds, st>>>(sp);
-    HIP_TRY(hipGetLastError());
-    KeyListSrc src{h->partial, np, k};
-    MergeOut mo{h->out_s, h->out_i, nullptr, k, h->qnorm, 0, h->metric, 0, nullptr, 0};
-    launch_merge(src, np, nq, k, merge_look(np, k, k), mo, st);
-    HIP_TRY(hipGetLastError());
+    if ((rc = ivf_search_locked(h, h->q_dev, nq, k, nprobe, h->out_s, h->out_i, st))) return rc;
     HIP_TRY(hipMemcpyAsync(out_scores, h->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_ids, h->out_i, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

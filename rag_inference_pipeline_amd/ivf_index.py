@@ -74,3 +74,13 @@ class IVFFlatIndex:
                                                D.ctypes.data_as(C.POINTER(C.c_float)),
                                                I.ctypes.data_as(C.POINTER(C.c_int64))))
         return D, I
+
+    def search_device(self, q_ptr: int, nq: int, k: int, scores_ptr: int, ids_ptr: int, stream: int = 0,
+                      nprobe: int | None = None) -> None:
+        """The same search on device pointers, enqueued on `stream` (rag_ivf_search_device): queries [nq][d] fp32,
+        scores [nq][k] fp32 and ids [nq][k] int64 in device memory; no host round trip."""
+        if not self._h:
+            raise RuntimeError("IVFFlatIndex is closed")
+        _native.check(self._lib.rag_ivf_search_device(self._h, C.c_void_p(q_ptr), int(nq), int(k),
+                                                      int(nprobe if nprobe is not None else self.nprobe),
+                                                      C.c_void_p(scores_ptr), C.c_void_p(ids_ptr), C.c_void_p(stream)))

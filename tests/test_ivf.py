@@ -80,8 +80,10 @@ def test_settings_carry_the_ivf_mode(monkeypatch):
     (60_000, 64, 4096, 1, 32, 10),      # the generator's shape of index (L2, nlist 4096), scaled down
     (60_000, 64, 4096, 0, 32, 100),
     (20_000, 384, 256, 1, 9, 10),
-    (5_000, 100, 300, 0, 3, 256),       # d not a multiple of 8, lists of a dozen rows, the largest k
+    (5_000, 100, 300, 0, 3, 256),       # d not a multiple of 8 (ring depth 1), lists of a dozen rows, k in two rounds
     (700, 32, 1000, 1, 5, 10),          # more lists than rows: most lists are empty
+    (40_000, 96, 200, 1, 70, 10),       # three passes of <= 32 queries (ring depth 4), lists of 200 rows = 7 tiles
+    (9_000, 768, 64, 0, 33, 120),       # the reference's dimension: k above one pass's 112 -> rounds; two passes
 ])
 def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlist, metric, nq, k):
     from rag_inference_pipeline_amd.flat_index import FlatIndex
@@ -105,8 +107,42 @@ def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlis
         np.testing.assert_array_equal(Ia, If)
         np.testing.assert_array_equal(Da.view(np.uint32), Df.view(np.uint32))
         flat.close()
-    with pytest.raises(Exception, match="256"):
-        idx.search(Q, 300)
+    # queries that share their lists (one row, asked 8 times, among others): a list is read once for all of them
+    Qs = np.concatenate([np.repeat(X[7:8], 8, axis=0), Q[: max(1, nq // 2)]])
+    D, I = idx.search(Qs, k, nprobe=5)
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Qs, k, 5, metric)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    with pytest.raises(Exception, match="2048"):
+        idx.search(Q, 3000)
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_hip_nprobe_search_on_device_pointers(gpu_required, tmp_path):
+    """rag_ivf_search_device: queries and results in device memory, enqueued on the caller's stream — the same bits as
+    the host-pointer entry point, batch after batch on one stream (the ticket counter is left at zero by every scan)."""
+    import torch
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    n, d, nlist, k = 30_000, 128, 512, 10
+    X, path = _file(tmp_path, n, d, nlist, 1, seed=5)
+    lists = index_io.read_ivfflat_lists(path)
+    idx = IVFFlatIndex(lists, nprobe=16)
+    stream = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(stream):
+        for rep, nq in enumerate((32, 1, 8, 32)):
+            Q = _unit(np.random.default_rng(100 + rep), nq, d)
+            q = torch.from_numpy(Q).cuda()
+            s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+            i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+            idx.search_device(q.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), stream.cuda_stream)
+            outs.append((Q, q, s, i))
+    stream.synchronize()
+    for Q, _, s, i in outs:
+        Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, 16, 1)
+        np.testing.assert_array_equal(i.cpu().numpy(), Io)
+        np.testing.assert_array_equal(s.cpu().numpy().view(np.uint32), Do.view(np.uint32))
     idx.close()
 
 
