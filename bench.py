@@ -52,6 +52,8 @@ def parse_args() -> argparse.Namespace:
                     help="skip the extra cross-encoder stage leg (32 x 100 synthetic (query, document) pairs)")
     ap.add_argument("--no-two-stage-leg", action="store_true",
                     help="skip the extra leg through the two-stage exact search (fp16 screen + fp32 second stage)")
+    ap.add_argument("--no-ivf-leg", action="store_true",
+                    help="skip the extra leg through the IVFFlat nprobe mode (4.5M x 768, nlist 4096, nprobe 64)")
     return ap.parse_args()
 
 
@@ -623,6 +625,32 @@ def main() -> None:
         legs_failed["rerank_stage"] = f"{type(exc).__name__}: {exc}"
         rerank_leg = None
 
+    # Extra leg (never `value`): the IVFFlat `nprobe` mode at the shape the reference's generator writes
+    # (scripts/create_test_docs.py:12,83-104: 4.5M x 768, L2, nlist 4096, nprobe 64) — opt-in RAG_AMD_IVF_MODE=nprobe.
+    # Bound: HBM, against the bytes of the UNION of a batch's probed lists (each list is read once per pass of 32 queries).
+    ivf_leg = None
+    try:
+        if world == 1 and not args.no_ivf_leg and d == 768:
+            import scripts.bench_ivf as bivf
+
+            base = dict(n=4_500_000, d=768, nlist=4096, nprobe=64, k=k, steps=20, warmup=3, exhaustive=False, unit=False)
+            clustered = bivf.run(argparse.Namespace(**base, batches="1,32", clustered=True))
+            generator = bivf.run(argparse.Namespace(**base, batches="32", clustered=False))
+            b32 = clustered["batches"]["32"]
+            ach = b32["union_bytes"] / b32["ms_per_batch"] / 1e6
+            ivf_leg = {"clustered_balanced_lists": clustered, "generator_gaussian_rows": generator,
+                       "roofline": {"bound": "hbm", "kernel": "ivf_batch_scan_kernel (whole search timed: coarse quantizer, plan, "
+                                    "list scan, merge)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_batch": b32["union_bytes"],
+                                    "workload": "clustered, batch 32", "kernel_only_source": "profiles/r04_ivf_nprobe.json"},
+                       "note": "generator_gaussian_rows: iid Gaussian rows have no cluster structure — k-means on 10 000 of "
+                               "them leaves most lists empty and a few huge, every query's 64 lists hold nearly the whole corpus "
+                               "and the mode costs what the exhaustive scan costs; clustered: rows from a mixture of 4096 "
+                               "centres, the regime an embedding corpus is in (a query's lists are 1.6 % of the rows)"}
+    except Exception as exc:  # noqa: BLE001
+        legs_failed["ivf_nprobe"] = f"{type(exc).__name__}: {exc}"
+        ivf_leg = None
+
     # Extra leg (never `value`): the same step through the two-stage exact search — fp16 screening scan
     # of a scaled copy of the corpus, canonical fp32 re-scoring of the band, per-query certificate,
     # device-side fp32 fallback (include/rag_amd.h rag_index_set_screening).  Same ids, same score bits.
@@ -785,6 +813,8 @@ def main() -> None:
             out["two_stage_exact"] = two_leg
         if rerank_leg is not None:
             out["rerank_stage"] = rerank_leg
+        if ivf_leg is not None:
+            out["ivf_nprobe"] = ivf_leg
         if legs_failed:
             out["legs_failed"] = legs_failed
         if world == 1 and not args.no_cpu_baseline:

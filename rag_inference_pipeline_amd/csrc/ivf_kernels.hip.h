@@ -106,6 +106,119 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
     if (t == 0) *p.n_items = base_s;
 }
 
+// ---- coarse quantizer: selection ------------------------------------------------------------------------------
+// The flat search over a few thousand centroids with k = nprobe = 64 is all fixed cost: 128 workgroups each emit a
+// 64-key list of their one tile and the tournament merge takes 64 rounds over 128 lists (45 + 35 us — more than a
+// batch-1 list scan).  Instead the flat scan kernel runs in its "park the inner products" mode (ScanParams.acc_out: the
+// canonical sums of every (centroid, query) pair go to acc[row][32], no selection) and this kernel picks the nprobe best
+// per query.  One workgroup per query; a wave sorts 8 chunks of 64 keys at once (the network's shuffle latencies overlap
+// across the sets), folds them pairwise — elementwise max against the partner list REVERSED leaves the 64 largest of the
+// union as a bitonic sequence, which takes the 6-stage merge network, not a 21-stage sort — and folds the survivor into
+// its running best; wave 0 folds the four waves' lists.  Same keys as the flat search: (score, ascending list number).
+
+// the last pass of the bitonic network: every one of the first `nsets` sets holds a bitonic sequence -> descending
+template <int E, int NQ>
+__device__ __forceinline__ void wave_merge_desc(u64 (&key)[NQ][E], int lane, int nsets) {
+#pragma unroll
+    for (int stride = 32 * E; stride > 0; stride >>= 1) {
+        if (stride >= 64) {
+            const int se = stride >> 6;
+#pragma unroll
+            for (int s = 0; s < NQ; ++s) {
+                if (s < nsets) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & se) == 0) {
+                            const u64 a = key[s][e], b = key[s][e | se];
+                            key[s][e] = umax64(a, b);
+                            key[s][e | se] = umin64(a, b);
+                        }
+                    }
+                }
+            }
+        } else {
+            u64 other[NQ][E];
+#pragma unroll
+            for (int s = 0; s < NQ; ++s)
+                if (s < nsets)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) other[s][e] = shfl_xor_u64(key[s][e], stride);
+            const bool lower = (lane & stride) == 0;
+#pragma unroll
+            for (int s = 0; s < NQ; ++s)
+                if (s < nsets)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) key[s][e] = lower ? umax64(key[s][e], other[s][e]) : umin64(key[s][e], other[s][e]);
+        }
+    }
+}
+
+// a <- the 64 E largest of (a U b), both sorted descending, as a bitonic sequence (index i of a meets index 64 E - 1 - i of b)
+template <int E>
+__device__ __forceinline__ void fold_reversed(u64 (&a)[E], const u64 (&b)[E], int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u64 v = b[E - 1 - e];
+        const uint32_t lo = __shfl((uint32_t)v, 63 - lane, 64), hi = __shfl((uint32_t)(v >> 32), 63 - lane, 64);
+        a[e] = umax64(a[e], ((u64)hi << 32) | lo);
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void ivf_coarse_select_kernel(const float* acc, const float* cnorm, const float* qnorm, int nlist,
+                                                               int np, int l2, long long* probe) {
+    constexpr int NB = 8 / E;      // chunks in flight per wave
+    constexpr int CH = 64 * E;     // keys per chunk
+    __shared__ u64 tops[4][CH];
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float t0 = RAGK_SCORE_FLOOR;
+    if (l2 && !(qnorm[q] <= 3.402823466e+38f)) t0 = __builtin_nanf("");   // every distance inf or NaN: no list is "nearest"
+    u64 top[1][E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) top[0][e] = 0ull;
+    for (int base = wave * NB * CH; base < nlist; base += 4 * NB * CH) {
+        u64 c[NB][E];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int row = base + s * CH + e * 64 + lane;
+                u64 key = 0ull;
+                if (row < nlist) {
+                    const float a = acc[(size_t)row * kQT + q];
+                    const float sc = l2 ? __builtin_fmaf(2.0f, a, -cnorm[row]) + 0.0f : a + 0.0f;
+                    if (sc >= t0) key = make_key(sc, (uint32_t)row);
+                }
+                c[s][e] = key;
+            }
+        }
+        wave_sort_desc<E, NB>(c, lane);
+#pragma unroll
+        for (int w = NB / 2; w >= 1; w >>= 1) {
+#pragma unroll
+            for (int s = 0; s < NB / 2; ++s)
+                if (s < w) fold_reversed<E>(c[s], c[s + w], lane);
+            wave_merge_desc<E, NB>(c, lane, w);
+        }
+        fold_reversed<E>(top[0], c[0], lane);
+        wave_merge_desc<E, 1>(top, lane, 1);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) tops[wave][e * 64 + lane] = top[0][e];
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < 4; ++w) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) top[0][e] = umax64(top[0][e], tops[w][(E - 1 - e) * 64 + 63 - lane]);
+        wave_merge_desc<E, 1>(top, lane, 1);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        if (j < np) probe[(size_t)q * np + j] = top[0][e] ? (long long)(0xFFFFFFFFu - (uint32_t)top[0][e]) : -1ll;
+    }
+}
+
 struct IvfBatchParams {
     const float* X;            // rows in padded list order, row_stride floats per row (columns zero-padded to d8)
     long long row_stride;

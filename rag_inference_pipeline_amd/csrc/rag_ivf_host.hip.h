@@ -18,6 +18,7 @@ struct rag_ivf {
     float* q_dev = nullptr; size_t q_cap = 0;
     float* qnorm = nullptr; size_t qn_cap = 0;
     float* c_scores = nullptr; long long* probe = nullptr; size_t probe_cap = 0;
+    float* c_acc = nullptr;           // [centroid tiles * 32][kQT] inner products of the coarse step (own selection)
     ragk::IvfItem* items = nullptr; size_t items_cap = 0;
     uint32_t* words = nullptr;        // [0] n_items, [1] ticket, [2] done (the scan kernel leaves [1], [2] at 0), [4 ...] shared thresholds (a line per query)
     ragk::u64* partial = nullptr; size_t partial_cap = 0;
@@ -76,7 +77,7 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         DeviceGuard g(h->device);
         std::lock_guard<std::mutex> lk(h->mu);
         (void)hipDeviceSynchronize();
-        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->items, h->words, h->partial,
+        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->c_acc, h->items, h->words, h->partial,
                         h->round_keys, h->out_s, h->out_i};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -197,13 +198,58 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
     if ((rc = ivf_grow(&h->items, &h->items_cap, (size_t)(h->rows_padded / kTileRows / kIvfItemTiles + h->nlist + 1)))) return rc;
     if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)kQT * grid * std::min(k, kmax)))) return rc;
     if (k > kmax && !h->round_keys && (rc = dev_alloc(&h->round_keys, (size_t)2 * kQT))) return rc;
-    // step 1: the coarse quantizer — the flat search over the centroids, nprobe nearest per query
-    rc = rag_index_search_device(h->coarse, q_dev, nq, np, h->c_scores, reinterpret_cast<int64_t*>(h->probe), (void*)st);
-    if (rc) return rc;
     const bool l2 = h->metric == RAG_METRIC_L2;
-    if (l2) {
+    const bool cl2 = h->coarse->metric == RAG_METRIC_L2;
+    if (l2 || cl2) {
         query_sqnorm_kernel<<<dim3(nq), dim3(64), (size_t)h->d8 * sizeof(float), st>>>(q_dev, h->d, h->qnorm);
         HIP_TRY(hipGetLastError());
+    }
+    // step 1: the coarse quantizer — the nprobe nearest centroids per query, ties by ascending list number.  Up to 256
+    // probes: the flat scan kernel parks the inner products and ivf_coarse_select_kernel ranks them (ivf_kernels.hip.h);
+    // more: the flat search itself
+    if (np <= 256) {
+        rag_index* c = h->coarse;
+        const int n_tiles = (int)((c->n + kTileRows - 1) / kTileRows);
+        if (!h->c_acc && (rc = dev_alloc(&h->c_acc, (size_t)n_tiles * kTileRows * kQT))) return rc;
+        const int grid = std::max(1, std::min(c->n_cus, n_tiles));
+        ScanFn fn = scan_fn(8, 64, pick_ring(c->d8 / 8), cl2);
+        const size_t lds = scan_lds_bytes(c->d8, 64);
+        if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
+        for (int b0 = 0; b0 < nq; b0 += kQT) {
+            const int nb = std::min(kQT, nq - b0);
+            ScanParams sp{};
+            sp.X = c->X;
+            sp.xnorm = c->xnorm;
+            sp.qnorm = h->qnorm + b0;
+            sp.Q = q_dev + (size_t)b0 * h->d;
+            sp.acc_io = h->c_acc;
+            sp.dc8 = c->d8;
+            sp.acc_out = 1;
+            sp.n_rows = c->n;
+            sp.row_stride = c->d8;
+            sp.d = c->d;
+            sp.d8 = c->d8;
+            sp.nq = nb;
+            sp.k = 1;
+            sp.kout = 1;
+            sp.n_tiles = n_tiles;
+            sp.n_iters = (n_tiles + grid * 8 - 1) / (grid * 8);
+            sp.n_full = n_tiles / (grid * 8);
+            sp.tile_step = 1;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
+            HIP_TRY(hipGetLastError());
+            long long* pr = h->probe + (size_t)b0 * np;
+            if (np <= 64)
+                ivf_coarse_select_kernel<1><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
+            else if (np <= 128)
+                ivf_coarse_select_kernel<2><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
+            else
+                ivf_coarse_select_kernel<4><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        rc = rag_index_search_device(h->coarse, q_dev, nq, np, h->c_scores, reinterpret_cast<int64_t*>(h->probe), (void*)st);
+        if (rc) return rc;
     }
     const bool share_thr = env_int("RAG_AMD_IVF_SHARED_THRESHOLDS", 1) != 0;   // (experiment switch; results do not depend on it)
     const int S = h->d8 / 8;

@@ -74,22 +74,10 @@ def build_lists(n: int, d: int, nlist: int, nprobe: int, unit: bool, clustered: 
     return lists, cent
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=4_500_000)
-    ap.add_argument("--d", type=int, default=768)
-    ap.add_argument("--nlist", type=int, default=4096)
-    ap.add_argument("--nprobe", type=int, default=64)
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--batches", default="1,8,32")
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--exhaustive", action="store_true")
-    ap.add_argument("--unit", action="store_true", help="unit-norm rows and queries (what an embedding model emits): "
-                    "balanced lists; the generator's Gaussian rows give very uneven ones")
-    ap.add_argument("--clustered", action="store_true", help="rows and queries from a mixture of nlist unit-norm centres, "
-                    "the centres as the quantizer: balanced lists, a query's nprobe lists are 1.6 %% of the corpus")
-    a = ap.parse_args()
+def run(a) -> dict:
+    """`a`: a namespace with n, d, nlist, nprobe, k, batches (comma list), steps, warmup, exhaustive, unit, clustered."""
+    global _CENTERS
+    _CENTERS = None
     from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
 
     t0 = time.time()
@@ -98,16 +86,17 @@ def main() -> None:
     t1 = time.time()
     idx = IVFFlatIndex(lists, nprobe=a.nprobe)
     t2 = time.time()
-    out = {"workload": f"IVFFlat L2 {a.n} x {a.d} fp32, nlist {a.nlist}, nprobe {a.nprobe}, k {a.k}; "
-                       f"{'clustered unit-norm rows (mixture of nlist centres = the quantizer)' if a.clustered else ('unit-norm' if a.unit else 'Gaussian') + ' rows, k-means on 10 000 training rows'}, nearest-centroid lists "
-                       "(reference scripts/create_test_docs.py:83-104)",
+    kind = ("clustered unit-norm rows (mixture of nlist centres = the quantizer)" if a.clustered else
+            ("unit-norm" if a.unit else "Gaussian") + " rows, k-means on 10 000 training rows")
+    out = {"workload": f"IVFFlat L2 {a.n} x {a.d} fp32, nlist {a.nlist}, nprobe {a.nprobe}, k {a.k}; {kind}, nearest-centroid "
+                       "lists (reference scripts/create_test_docs.py:83-104)",
            "list_rows": {"mean": float(sizes.mean()), "min": int(sizes.min()), "max": int(sizes.max()),
                          "empty_lists": int((sizes == 0).sum())},
            "build_s": round(t1 - t0, 1), "set_lists_s": round(t2 - t1, 1), "batches": {}}
     stream = torch.cuda.Stream()
     g = torch.Generator(device="cuda").manual_seed(99)
     cn = (cent * cent).sum(1)
-    for nq in [int(b) for b in a.batches.split(",")]:
+    for nq in [int(b) for b in str(a.batches).split(",")]:
         sets = [draw((nq, a.d), g, a.unit) for _ in range(8)]
         s = torch.empty((nq, a.k), dtype=torch.float32, device="cuda")
         i = torch.empty((nq, a.k), dtype=torch.int64, device="cuda")
@@ -132,7 +121,8 @@ def main() -> None:
         out["batches"][str(nq)] = {"ms_per_batch": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1),
                                    "union_bytes": int(ub), "pair_bytes": int(pb),
                                    "search_gbps_vs_union": round(ub / ms / 1e6, 1),
-                                   "corpus_fraction_read": round(ub / (a.n * a.d * 4.0), 4)}
+                                   "corpus_fraction_read": round(ub / (a.n * a.d * 4.0), 4),
+                                   "id_checksum": int(i.sum().item())}
         print(f"nq={nq}: {ms:.4f} ms/batch, union {ub / 1e9:.3f} GB -> {ub / ms / 1e6:.0f} GB/s (whole search)", file=sys.stderr)
     if a.exhaustive:
         from rag_inference_pipeline_amd.flat_index import FlatIndex
@@ -140,7 +130,7 @@ def main() -> None:
         for r0 in range(0, a.n, 1 << 20):
             flat.add(lists.rows[r0:r0 + (1 << 20)])
         ex = {}
-        for nq in [int(b) for b in a.batches.split(",")]:
+        for nq in [int(b) for b in str(a.batches).split(",")]:
             q = draw((nq, a.d), g, a.unit)
             s = torch.empty((nq, a.k), dtype=torch.float32, device="cuda")
             i = torch.empty((nq, a.k), dtype=torch.int64, device="cuda")
@@ -157,7 +147,27 @@ def main() -> None:
         out["exhaustive_flat_ms_per_batch"] = ex
         flat.close()
     idx.close()
-    print(json.dumps(out))
+    _CENTERS = None
+    del lists, cent
+    torch.cuda.empty_cache()
+    return out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4_500_000)
+    ap.add_argument("--d", type=int, default=768)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=64)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--batches", default="1,8,32")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--exhaustive", action="store_true")
+    ap.add_argument("--unit", action="store_true", help="unit-norm rows and queries (what an embedding model emits)")
+    ap.add_argument("--clustered", action="store_true", help="rows and queries from a mixture of nlist unit-norm centres, "
+                    "the centres as the quantizer: balanced lists, a query's nprobe lists are 1.6 %% of the corpus")
+    print(json.dumps(run(ap.parse_args())))
 
 
 if __name__ == "__main__":

@@ -94,7 +94,7 @@ def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlis
     Q[0] = X[123 % n]                                           # a query that is a corpus row
     idx = IVFFlatIndex(lists, nprobe=8)
     assert (idx.ntotal, idx.nlist, idx.nprobe) == (n, nlist, 8)
-    for nprobe in (1, 8, 64):
+    for nprobe in (1, 8, 64, 100, 200):   # (the coarse selection keeps 64, 128 or 256 keys per wave)
         D, I = idx.search(Q, k, nprobe=nprobe)
         Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, metric)
         np.testing.assert_array_equal(I, Io)
