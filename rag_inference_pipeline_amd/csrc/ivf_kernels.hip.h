@@ -8,9 +8,10 @@
 //
 //   * rows live in LIST order, every list padded to whole 32-row tiles (padding rows are zeros with id 0xFFFFFFFF), so a
 //     wave's tile never straddles two lists;
-//   * `ivf_plan_kernel` (one workgroup) turns a pass's probe table [nq <= 32][nprobe] into per-list query MASKS and a work
-//     list of items = up to 8 consecutive tiles of a list that at least one query probes.  A list probed by several
-//     queries of the batch is read ONCE;
+//   * `ivf_plan_kernel` (one workgroup) turns a pass's probe table [nq <= 32][nprobe] into per-list query MASKS and the
+//     packed sequence of (tile, mask) entries of every list that at least one query probes; a work ITEM is 8 consecutive
+//     entries — whole items whatever the lists' lengths (lists of 9 tiles would otherwise run as 8 + 1).  A list probed
+//     by several queries of the batch is read ONCE;
 //   * `ivf_batch_scan_kernel` (one 8-wave workgroup per CU, items dealt by ticket): a wave multiplies its 32-row tile
 //     with ALL 32 queries of the pass on v_mfma_f32_32x32x2_f32 — the flat scan's inner loop, hence the flat search's
 //     canonical summation order and score bits — and lanes of queries that do not probe the item's list drop their
@@ -32,31 +33,34 @@ constexpr int kIvfItemTiles = 8;                // tiles per work item = waves p
 constexpr int kIvfMaxLists = 32768;             // the plan kernel keeps one mask word per list in LDS
 constexpr int kIvfThrStride = 32;               // words between two queries' shared thresholds: a 128-byte line each
 
-struct IvfItem {          // 16 bytes: one ticket's work
-    uint32_t first_tile;  // global tile number (rows 32 * first_tile ...)
-    uint32_t n_tiles;     // 1..8; 0 = no more items
-    uint32_t mask;        // bit q: query q of the pass probes this list
-    uint32_t list;
+struct IvfTile {      // 8 bytes: one wave's work in an item
+    uint32_t tile;    // global tile number (rows 32 * tile ...), kIvfNoTile = none
+    uint32_t mask;    // bit q: query q of the pass probes the tile's list
 };
+constexpr uint32_t kIvfNoTile = 0xFFFFFFFFu;
 
 struct IvfPlanParams {
     const long long* probe;     // [nq][nprobe] list numbers from the coarse search, -1 = none
     const uint32_t* tile_off;   // [nlist + 1] first tile of each list (padded layout)
-    IvfItem* items;             // out: [<= n_tiles / 8 + nlist]
-    uint32_t* n_items;          // out
+    IvfTile* tiles;             // out: the probed lists' tiles, packed ([<= all tiles])
+    uint32_t* n_tiles;          // out
     uint32_t* gthr;             // [kQT * kIvfThrStride] the scan's shared thresholds: zeroed here
     int nq, nprobe, nlist;
 };
 
-// One workgroup of 1024 threads: masks in LDS, then lists 1024 at a time: items per list -> running prefix -> item records.
+// One workgroup of 1024 threads: masks in LDS, then lists 1024 at a time: tiles per probed list -> running prefix -> entries.
 __global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
     extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
     uint32_t* mask = reinterpret_cast<uint32_t*>(ivf_smem);   // [nlist]
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t base_s;
+    __shared__ uint32_t base_s, n_big;
+    __shared__ uint32_t big[256][4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int l = t; l < p.nlist; l += 1024) mask[l] = 0u;
-    if (t == 0) base_s = 0u;
+    if (t == 0) {
+        base_s = 0u;
+        n_big = 0u;
+    }
     if (t < kQT) p.gthr[t * kIvfThrStride] = 0u;
     __syncthreads();
     const int np = p.nq * p.nprobe;
@@ -71,10 +75,9 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
         if (l < p.nlist) {
             m = mask[l];
             ft = p.tile_off[l];
-            nt = p.tile_off[l + 1] - ft;
+            nt = m ? p.tile_off[l + 1] - ft : 0u;
         }
-        const uint32_t ng = m ? (nt + kIvfItemTiles - 1) / kIvfItemTiles : 0u;
-        uint32_t incl = ng;   // inclusive prefix within the wave
+        uint32_t incl = nt;   // inclusive prefix within the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o, 64);
@@ -84,26 +87,42 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
         __syncthreads();
         uint32_t before = base_s;
         for (int w = 0; w < wave; ++w) before += wsum[w];
-        const uint32_t at = before + incl - ng;
-        // the records of a list are written by the whole wave (the generator's Gaussian rows put 800 000 of 4.5M rows —
-        // 3000 items — into one list: written by the list's own thread that was 0.3 ms of a 2.9 ms search)
-        unsigned long long todo = __ballot(ng != 0u);
+        const uint32_t at = before + incl - nt;
+        // the entries of a list are written by the whole wave, those of a long list (the generator's Gaussian rows put
+        // 800 000 of 4.5M rows — 25 000 tiles — into one) by the whole workgroup
+        const bool is_big = nt > 512u;
+        if (is_big) {
+            const uint32_t slot = atomicAdd(&n_big, 1u);
+            if (slot < 256u) {
+                big[slot][0] = ft;
+                big[slot][1] = nt;
+                big[slot][2] = m;
+                big[slot][3] = at;
+            }
+        }
+        __syncthreads();
+        const bool big_fits = n_big <= 256u;   // (else every list goes the wave's way)
+        unsigned long long todo = __ballot(nt != 0u && !(is_big && big_fits));
         while (todo) {
             const int src = __builtin_ctzll(todo);
             todo &= todo - 1;
             const uint32_t l_ft = __shfl(ft, src, 64), l_nt = __shfl(nt, src, 64), l_m = __shfl(m, src, 64);
-            const uint32_t l_ng = __shfl(ng, src, 64), l_at = __shfl(at, src, 64);
-            for (uint32_t j = lane; j < l_ng; j += 64) {
-                const uint32_t left = l_nt - j * kIvfItemTiles;
-                p.items[l_at + j] = IvfItem{l_ft + j * kIvfItemTiles, left < (uint32_t)kIvfItemTiles ? left : (uint32_t)kIvfItemTiles, l_m,
-                                            (uint32_t)(l0 + 64 * wave + src)};
+            const uint32_t l_at = __shfl(at, src, 64);
+            for (uint32_t j = lane; j < l_nt; j += 64) p.tiles[l_at + j] = IvfTile{l_ft + j, l_m};
+        }
+        if (big_fits) {
+            for (uint32_t b = 0; b < n_big; ++b) {
+                const uint32_t l_ft = big[b][0], l_nt = big[b][1], l_m = big[b][2], l_at = big[b][3];
+                for (uint32_t j = t; j < l_nt; j += 1024) p.tiles[l_at + j] = IvfTile{l_ft + j, l_m};
             }
         }
+        __syncthreads();
+        if (t == 0) n_big = 0u;
         __syncthreads();
         if (t == 1023) base_s = before + incl;
         __syncthreads();
     }
-    if (t == 0) *p.n_items = base_s;
+    if (t == 0) *p.n_tiles = base_s;
 }
 
 // ---- coarse quantizer: selection ------------------------------------------------------------------------------
@@ -226,8 +245,8 @@ struct IvfBatchParams {
     const uint32_t* ids;       // [rows] stored id, kIvfPadId for padding rows
     const float* Q;            // [nq][d]
     const float* qnorm;        // [nq] (L2): a non-finite one means no results
-    const IvfItem* items;
-    const uint32_t* n_items;
+    const IvfTile* tiles;      // the pass's packed (tile, mask) entries: item g = entries [8 g, 8 g + 8)
+    const uint32_t* n_tiles;
     uint32_t* ticket;          // 0 at launch; the last workgroup to leave zeroes it again
     uint32_t* done;            // workgroups that have left (same)
     u64* partial;              // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
@@ -237,9 +256,9 @@ struct IvfBatchParams {
     int d, d8, nq, k, l2;
 };
 
-// LDS: [Q fragments d8 * 128 B][keys 32 * C * 8 B][cnt 32][thr 32][flag 4][item records 2 x 4 words][sequence word + pad]
+// LDS: [Q fragments d8 * 128 B][keys 32 * C * 8 B][cnt 32][thr 32][flag 4][item records 2 x 8 entries][sequence word + pad]
 __host__ __device__ inline size_t ivf_scan_lds_bytes(int d8, int C) {
-    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + 32 + 16;
+    return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + 128 + 16;
 }
 
 // E = candidate buffer capacity / 64, D = register ring depth (steps of 32 bytes per row in flight per wave).
@@ -259,29 +278,36 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
     uint32_t* cnt = reinterpret_cast<uint32_t*>(keys + (size_t)kQT * C);
     float* thr = reinterpret_cast<float*>(cnt + kQT);
     uint32_t* flag = reinterpret_cast<uint32_t*>(thr + kQT);
-    // the item of iteration it sits in itemw[4 (it & 1) ..]; itemw[8] = the newest iteration whose item is posted.
-    // Thread 0 writes record then number, readers read number then record (LDS operations of a wave execute in order)
+    // the item of iteration it sits in itemw[16 (it & 1) ..] (8 entries of two words); itemw[32] = the newest iteration
+    // whose item is posted.  Lanes 0-7 of wave 0 write entries then number, readers read number then entries (LDS
+    // operations of a wave execute in order)
     volatile uint32_t* itemw = reinterpret_cast<volatile uint32_t*>(flag + 4);
 
-    // ---- the deal.  Item i of the work list: iteration 0 of workgroup b takes item b, iteration 1 item grid + b, every
-    // later one the item of a TICKET (item = ticket + 2 grid) drawn from one global counter.  Thread 0 runs a three-deep
-    // pipeline at the TOP of each iteration — post the record fetched an iteration ago (for iteration it + 1), fetch the
-    // record of the ticket drawn an iteration ago (it + 2), draw the next ticket (it + 3) — so every returning memory
-    // operation has a whole tile time before its result is used, and the use sits right behind the iteration's barrier,
-    // where the wave's load queue is drained anyway (vmcnt counts in order: a wait for the ticket in the middle of the
-    // K loop would be a wait for the whole register ring).
-    uint32_t n_items = 0u, g_pend = 0u;
-    IvfItem rec_pend{0u, 0u, 0u, 0u};
-    if (tid == 0) {
-        n_items = *p.n_items;
-        IvfItem rec0{0u, 0u, 0u, 0u};
-        if (blockIdx.x < n_items) rec0 = p.items[blockIdx.x];
-        if (gridDim.x + blockIdx.x < n_items) rec_pend = p.items[gridDim.x + blockIdx.x];
-        g_pend = atomicAdd(p.ticket, 1u);
-        itemw[0] = rec0.first_tile;
-        itemw[1] = rec0.n_tiles;
-        itemw[2] = rec0.mask;
-        itemw[8] = 0u;
+    // ---- the deal.  Item g = entries [8 g, 8 g + 8) of the packed tile sequence, entry w for wave w.  Iteration 0 of
+    // workgroup b takes item b, iteration 1 item grid + b, every later one the item of a TICKET (item = ticket + 2 grid)
+    // drawn from one global counter.  Lanes 0-7 of wave 0 run a three-deep pipeline at the TOP of each iteration — post
+    // the entries fetched an iteration ago (for iteration it + 1), fetch the entries of the ticket drawn an iteration ago
+    // (it + 2), draw the next ticket (it + 3; lane 0) — so every returning memory operation has a whole tile time before
+    // its result is used, and the use sits right behind the iteration's barrier, where the wave's load queue is drained
+    // anyway (vmcnt counts in order: a wait for the ticket in the middle of the K loop would be a wait for the whole
+    // register ring).
+    const bool dealer = wave == 0 && lane < NW;
+    uint32_t n_tiles = 0u, g_pend = 0u;
+    IvfTile rec_pend{kIvfNoTile, 0u};
+    auto fetch = [&](uint32_t item) -> IvfTile {   // dealer lanes: this lane's entry of `item`
+        const uint32_t v = item * NW + lane;
+        IvfTile e{kIvfNoTile, 0u};
+        if (item < 0x10000000u && v < n_tiles) e = p.tiles[v];
+        return e;
+    };
+    if (dealer) {
+        n_tiles = *p.n_tiles;
+        const IvfTile rec0 = fetch(blockIdx.x);
+        rec_pend = fetch(gridDim.x + blockIdx.x);
+        if (lane == 0) g_pend = atomicAdd(p.ticket, 1u);
+        itemw[2 * lane] = rec0.tile;
+        itemw[2 * lane + 1] = rec0.mask;
+        if (lane == 0) itemw[32] = 0u;
     }
 
     // ---- prologue: queries -> MFMA B fragments in LDS: fragment (s, l) = Q[l & 31][8 s + 4 (l >> 5) .. + 3]
@@ -330,29 +356,28 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
     const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
     auto row_ptr = [&](uint32_t tile) -> const float* { return p.X + ((long long)tile * kTileRows + r) * p.row_stride + 4 * h; };
 
-    uint32_t first = itemw[0], ntl = itemw[1], imask = itemw[2];   // iteration 0's item (posted before the barrier)
+    // iteration 0's item (posted before the barrier): this wave's entry, and entry 0 (none = no more items)
+    uint32_t tile = __builtin_amdgcn_readfirstlane(itemw[2 * wave]), imask = __builtin_amdgcn_readfirstlane(itemw[2 * wave + 1]);
+    bool more = __builtin_amdgcn_readfirstlane(itemw[0]) != kIvfNoTile;
     f32x4 xb[D];
     const float* pc = p.X;
-    bool active = (uint32_t)wave < ntl;
+    bool active = tile != kIvfNoTile;
     if (active) {
-        pc = row_ptr(first + wave);
+        pc = row_ptr(tile);
 #pragma unroll
         for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
     }
 
     uint32_t seq = 0, g_seen = 0u;
-    for (int it = 0; ntl != 0u; ++it) {   // workgroup-uniform
-        if (tid == 0) {
-            volatile uint32_t* w = itemw + 4 * ((it + 1) & 1);
-            w[0] = rec_pend.first_tile;
-            w[1] = rec_pend.n_tiles;
-            w[2] = rec_pend.mask;
-            itemw[8] = (uint32_t)(it + 1);
-            const uint32_t idx = g_pend + 2u * gridDim.x;
-            IvfItem nx{0u, 0u, 0u, 0u};
-            if (idx < n_items) nx = p.items[idx];
-            rec_pend = nx;
-            g_pend = atomicAdd(p.ticket, 1u);
+    for (int it = 0; more; ++it) {   // workgroup-uniform
+        if (dealer) {
+            volatile uint32_t* w = itemw + 16 * ((it + 1) & 1);
+            w[2 * lane] = rec_pend.tile;
+            w[2 * lane + 1] = rec_pend.mask;
+            if (lane == 0) itemw[32] = (uint32_t)(it + 1);   // (a wave's LDS writes complete in order)
+            const uint32_t g = __builtin_amdgcn_readfirstlane(g_pend);
+            rec_pend = fetch(g + 2u * gridDim.x);
+            if (lane == 0) g_pend = atomicAdd(p.ticket, 1u);
         }
         // Shared thresholds.  A workgroup meets a given query in one or two of its ~30 items (a query probes 64 of the
         // batch's ~1600 lists), so a filter that learns only from the workgroup's own rows stays cold: every first meeting
@@ -368,20 +393,20 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
             }
             g_seen = __hip_atomic_load(p.gthr + lane * kIvfThrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const uint32_t tile = first + wave;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
         constexpr int G = D >= 4 ? 4 : D;
-        uint32_t first_n = 0u, ntl_n = 0u, imask_n = 0u;
+        uint32_t tile_n = kIvfNoTile, imask_n = 0u;
+        bool more_n = false;
         auto read_next = [&]() {
-            while (itemw[8] != (uint32_t)(it + 1)) {
+            while (itemw[32] != (uint32_t)(it + 1)) {
             }
-            volatile uint32_t* w = itemw + 4 * ((it + 1) & 1);
-            first_n = __builtin_amdgcn_readfirstlane(w[0]);
-            ntl_n = __builtin_amdgcn_readfirstlane(w[1]);
-            imask_n = __builtin_amdgcn_readfirstlane(w[2]);
+            volatile uint32_t* w = itemw + 16 * ((it + 1) & 1);
+            tile_n = __builtin_amdgcn_readfirstlane(w[2 * wave]);
+            imask_n = __builtin_amdgcn_readfirstlane(w[2 * wave + 1]);
+            more_n = __builtin_amdgcn_readfirstlane(w[0]) != kIvfNoTile;
         };
         if (active) {   // wave-uniform
             f32x4 qcur = qf[lane];
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
             }
             read_next();
             // last D steps: the ring refills from this wave's tile of the next item (or once more from this one's start)
-            const float* pn = (uint32_t)wave < ntl_n ? row_ptr(first_n + wave) : pc;
+            const float* pn = tile_n != kIvfNoTile ? row_ptr(tile_n) : pc;
             {
                 const f32x4* qs = qf + (size_t)(s0 + 1) * 64 + lane;
 #pragma unroll
@@ -431,8 +456,8 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
             pc = pn;
         } else {
             read_next();
-            if ((uint32_t)wave < ntl_n) {
-                pc = row_ptr(first_n + wave);
+            if (tile_n != kIvfNoTile) {
+                pc = row_ptr(tile_n);
 #pragma unroll
                 for (int i = 0; i < D; ++i) xb[i] = *reinterpret_cast<const f32x4*>(pc + 8 * i);
             }
@@ -546,10 +571,10 @@ __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParam
                 pending = still;
             }
         }
-        first = first_n;
-        ntl = ntl_n;
+        tile = tile_n;
         imask = imask_n;
-        active = (uint32_t)wave < ntl;
+        more = more_n;
+        active = tile != kIvfNoTile;
     }
 
     // ---- epilogue: sort every buffer, emit k keys per query for this workgroup

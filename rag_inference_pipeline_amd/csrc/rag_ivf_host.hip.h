@@ -19,8 +19,8 @@ struct rag_ivf {
     float* qnorm = nullptr; size_t qn_cap = 0;
     float* c_scores = nullptr; long long* probe = nullptr; size_t probe_cap = 0;
     float* c_acc = nullptr;           // [centroid tiles * 32][kQT] inner products of the coarse step (own selection)
-    ragk::IvfItem* items = nullptr; size_t items_cap = 0;
-    uint32_t* words = nullptr;        // [0] n_items, [1] ticket, [2] done (the scan kernel leaves [1], [2] at 0), [4 ...] shared thresholds (a line per query)
+    ragk::IvfTile* tiles = nullptr; size_t tiles_cap = 0;   // a pass's packed (tile, mask) entries
+    uint32_t* words = nullptr;        // [0] entries of the pass, [1] ticket, [2] done (the scan kernel leaves [1], [2] at 0), [4 ...] shared thresholds (a line per query)
     ragk::u64* partial = nullptr; size_t partial_cap = 0;
     ragk::u64* round_keys = nullptr;  // 2 x kQT keys (k > max_k rounds)
     float* out_s = nullptr; long long* out_i = nullptr; size_t out_cap = 0;
@@ -77,7 +77,7 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         DeviceGuard g(h->device);
         std::lock_guard<std::mutex> lk(h->mu);
         (void)hipDeviceSynchronize();
-        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->c_acc, h->items, h->words, h->partial,
+        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->c_acc, h->tiles, h->words, h->partial,
                         h->round_keys, h->out_s, h->out_i};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -195,7 +195,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
         if ((rc = ivf_grow(&h->c_scores, &cap2, (size_t)nq * np))) return rc;
         if ((rc = ivf_grow(&h->probe, &h->probe_cap, (size_t)nq * np))) return rc;
     }
-    if ((rc = ivf_grow(&h->items, &h->items_cap, (size_t)(h->rows_padded / kTileRows / kIvfItemTiles + h->nlist + 1)))) return rc;
+    if ((rc = ivf_grow(&h->tiles, &h->tiles_cap, (size_t)(h->rows_padded / kTileRows + 1)))) return rc;
     if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)kQT * grid * std::min(k, kmax)))) return rc;
     if (k > kmax && !h->round_keys && (rc = dev_alloc(&h->round_keys, (size_t)2 * kQT))) return rc;
     const bool l2 = h->metric == RAG_METRIC_L2;
@@ -257,7 +257,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
     for (int b0 = 0; b0 < nq; b0 += kQT) {
         const int nb = std::min(kQT, nq - b0);
         // step 2: this pass's probe table -> list masks -> work items
-        IvfPlanParams pp{h->probe + (size_t)b0 * np, h->tile_off, h->items, h->words, h->words + 32, nb, np, (int)h->nlist};
+        IvfPlanParams pp{h->probe + (size_t)b0 * np, h->tile_off, h->tiles, h->words, h->words + 32, nb, np, (int)h->nlist};
         ivf_plan_kernel<<<dim3(1), dim3(1024), (size_t)h->nlist * sizeof(uint32_t), st>>>(pp);
         HIP_TRY(hipGetLastError());
         // step 3: the probed lists, each read once, against the pass's queries; step 4: merge of the workgroups' lists
@@ -267,7 +267,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             const int cap = ivf_capacity(h->d8, kr);
             const u64* ceil = done ? h->round_keys + (size_t)flip * kQT : nullptr;
             u64* last = k > kmax ? h->round_keys + (size_t)(flip ^ 1) * kQT : nullptr;
-            IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_dev + (size_t)b0 * h->d, h->qnorm + b0, h->items, h->words, h->words + 1,
+            IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_dev + (size_t)b0 * h->d, h->qnorm + b0, h->tiles, h->words, h->words + 1,
                               h->words + 2, h->partial, ceil, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr, l2 ? 1 : 0};
             if (done) HIP_TRY(hipMemsetAsync(h->words + 32, 0, kQT * kIvfThrStride * sizeof(uint32_t), st));   // a round's thresholds bind that round's candidates only
             IvfScanFn fn = ivf_scan_fn(cap, ring);
