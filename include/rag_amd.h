@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 6
+#define RAG_AMD_ABI_VERSION 7
 
 /* status codes */
 #define RAG_OK 0
@@ -285,6 +285,10 @@ int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k,
  * round trip — the form the embedder's device hand-off uses (rag_index_search_device's contract). */
 int rag_ivf_search_device(rag_ivf* h, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
                           float* out_scores_dev, int64_t* out_ids_dev, void* stream);
+/* Device queries in (an embedder's result, still on `stream`), host results out; blocks until they are there
+ * (rag_index_search_device_host_out's contract). */
+int rag_ivf_search_device_host_out(rag_ivf* h, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                                   float* out_scores, int64_t* out_ids, void* stream);
 
 /* ---- C1: the shard step's collectives on an own RCCL communicator (SURVEY §8a "C1", §8e) ------------------- */
 

@@ -235,6 +235,7 @@ def signatures() -> dict:
         "rag_ivf_nlist": (C.c_int64, [vp]),
         "rag_ivf_search": (C.c_int, [vp, f32p, C.c_int32, C.c_int32, C.c_int32, f32p, i64p]),
         "rag_ivf_search_device": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
+        "rag_ivf_search_device_host_out": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, f32p, i64p, vp]),
         "rag_comm_runtime": (C.c_int, [C.c_char_p, i32p]),
         "rag_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
         "rag_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]),

@@ -173,6 +173,11 @@ class FAISSStore:
         try:
             if self._ivf is not None:
                 if isinstance(embeddings, DeviceEmbeddings):
+                    if embeddings.device == self._ivf.device:   # the embedder's result never left HBM (as below)
+                        res = self._ivf.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, embeddings.stream)
+                        embeddings.settled()
+                        if embeddings.valid():
+                            return res
                     embeddings = embeddings.numpy()
                 return self._ivf.search(np.ascontiguousarray(embeddings, dtype=np.float32), k)
             if isinstance(embeddings, DeviceEmbeddings):

@@ -306,6 +306,23 @@ extern "C" int rag_ivf_search_device(rag_ivf* h, const float* queries_dev, int32
     return ivf_search_locked(h, queries_dev, nq, k, nprobe, out_scores_dev, reinterpret_cast<long long*>(out_ids_dev), (hipStream_t)stream);
 }
 
+namespace {
+// results of a search on `st` to host memory: one read-back per array, one wait
+int ivf_search_to_host(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe, float* out_scores, int64_t* out_ids, hipStream_t st) {
+    int rc;
+    {
+        size_t cap2 = h->out_cap;
+        if ((rc = ivf_grow(&h->out_s, &cap2, (size_t)nq * k))) return rc;
+        if ((rc = ivf_grow(&h->out_i, &h->out_cap, (size_t)nq * k))) return rc;
+    }
+    if ((rc = ivf_search_locked(h, q_dev, nq, k, nprobe, h->out_s, h->out_i, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_scores, h->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_ids, h->out_i, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RAG_OK;
+}
+}  // namespace
+
 extern "C" int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq, int32_t k, int32_t nprobe,
                               float* out_scores, int64_t* out_ids) {
     int rc = ivf_check_args(h, queries_host, nq, k, nprobe, out_scores, out_ids);
@@ -314,15 +331,15 @@ extern "C" int rag_ivf_search(rag_ivf* h, const float* queries_host, int32_t nq,
     std::lock_guard<std::mutex> lk(h->mu);
     hipStream_t st = h->stream;
     if ((rc = ivf_grow(&h->q_dev, &h->q_cap, (size_t)nq * h->d))) return rc;
-    {
-        size_t cap2 = h->out_cap;
-        if ((rc = ivf_grow(&h->out_s, &cap2, (size_t)nq * k))) return rc;
-        if ((rc = ivf_grow(&h->out_i, &h->out_cap, (size_t)nq * k))) return rc;
-    }
     HIP_TRY(hipMemcpyAsync(h->q_dev, queries_host, (size_t)nq * h->d * sizeof(float), hipMemcpyHostToDevice, st));
-    if ((rc = ivf_search_locked(h, h->q_dev, nq, k, nprobe, h->out_s, h->out_i, st))) return rc;
-    HIP_TRY(hipMemcpyAsync(out_scores, h->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_ids, h->out_i, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RAG_OK;
+    return ivf_search_to_host(h, h->q_dev, nq, k, nprobe, out_scores, out_ids, st);
+}
+
+extern "C" int rag_ivf_search_device_host_out(rag_ivf* h, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                                              float* out_scores, int64_t* out_ids, void* stream) {
+    int rc = ivf_check_args(h, queries_dev, nq, k, nprobe, out_scores, out_ids);
+    if (rc || nq == 0) return rc;
+    DeviceGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->mu);
+    return ivf_search_to_host(h, queries_dev, nq, k, nprobe, out_scores, out_ids, (hipStream_t)stream);
 }

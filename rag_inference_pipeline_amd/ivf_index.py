@@ -84,3 +84,16 @@ class IVFFlatIndex:
         _native.check(self._lib.rag_ivf_search_device(self._h, C.c_void_p(q_ptr), int(nq), int(k),
                                                       int(nprobe if nprobe is not None else self.nprobe),
                                                       C.c_void_p(scores_ptr), C.c_void_p(ids_ptr), C.c_void_p(stream)))
+
+    def search_from_device(self, q_ptr: int, nq: int, k: int, stream: int = 0,
+                           nprobe: int | None = None) -> tuple[np.ndarray, np.ndarray]:
+        """(D, I) on the host for queries that are already in device memory (an embedder's device-resident result on
+        `stream`): rag_ivf_search_device_host_out — one read-back per array, one wait."""
+        if not self._h:
+            raise RuntimeError("IVFFlatIndex is closed")
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _native.check(self._lib.rag_ivf_search_device_host_out(
+            self._h, C.c_void_p(q_ptr), int(nq), int(k), int(nprobe if nprobe is not None else self.nprobe),
+            D.ctypes.data_as(C.POINTER(C.c_float)), I.ctypes.data_as(C.POINTER(C.c_int64)), C.c_void_p(stream)))
+        return D, I

@@ -12,6 +12,6 @@ mkdir -p "$OUT"
 python "$ROOT/bench.py" > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 tail -c 600 "$OUT/bench_n1.json"; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats" -o bench -- python3 "$ROOT/bench.py" --steps 20 --no-cpu-baseline --no-encoder-leg --no-rerank-leg > "$OUT/bench_under_rocprof.json" 2> "$OUT/kstats.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc" -o bench -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --latency-steps 0 --no-cpu-baseline --no-encoder-leg --no-rerank-leg > "$OUT/bench_under_pmc.json" 2> "$OUT/pmc.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats" -o bench -- python3 "$ROOT/bench.py" --steps 20 --no-cpu-baseline --no-encoder-leg --no-rerank-leg --no-ivf-leg > "$OUT/bench_under_rocprof.json" 2> "$OUT/kstats.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc" -o bench -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --latency-steps 0 --no-cpu-baseline --no-encoder-leg --no-rerank-leg --no-ivf-leg > "$OUT/bench_under_pmc.json" 2> "$OUT/pmc.err"
 ls "$OUT/kstats" "$OUT/pmc"

@@ -161,6 +161,15 @@ def test_faiss_store_nprobe_mode_end_to_end(gpu_required, tmp_path):
     Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, 10, 4, 1)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    # the embedder's device hand-off: queries that never left HBM, on the producer's stream (rag_ivf_search_device_host_out)
+    import torch
+    from rag_inference_pipeline_amd.device_embeddings import DeviceEmbeddings
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        qt = torch.from_numpy(Q).cuda()
+    Dd, Id = store.search(DeviceEmbeddings(qt, stream.cuda_stream, 0), 10)
+    np.testing.assert_array_equal(Id, Io)
+    np.testing.assert_array_equal(Dd.view(np.uint32), Do.view(np.uint32))
     store.unload()
     exhaustive = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(path), faiss_dim=d))   # the default: every list
     exhaustive.load()
