@@ -133,8 +133,8 @@ class FAISSStore:
             raise RuntimeError(f"FAISS index loading failed: {exc}") from exc
 
     def _load_ivf_nprobe_mode(self) -> bool:
-        """RAG_AMD_IVF_MODE=nprobe on an IndexIVFFlat file, one GPU: keep the inverted lists and search as the reference
-        does with index.nprobe = FAISS_NPROBE (faiss_store.py:84-92).  False: the caller loads the file exhaustively."""
+        """RAG_AMD_IVF_MODE=nprobe on an IndexIVFFlat file: keep the inverted lists and search as the reference does with
+        index.nprobe = FAISS_NPROBE (faiss_store.py:84-92).  False: the caller loads the file exhaustively."""
         mode = str(getattr(self.settings, "faiss_ivf_mode", "exhaustive")).strip().lower()
         if mode not in ("exhaustive", "nprobe"):
             raise ValueError(f"RAG_AMD_IVF_MODE must be 'exhaustive' or 'nprobe', got {mode!r}")
@@ -143,19 +143,26 @@ class FAISSStore:
         with open(self.index_path, "rb") as fh:
             if fh.read(4) != b"IwFl":
                 return False   # not an IVF file: nprobe has no meaning, as for the reference's flat indexes (:84)
-        if self._dist_rank_world()[1] > 1:
-            logger.warning("RAG_AMD_IVF_MODE=nprobe is a one-GPU mode; the sharded deployment searches exhaustively")
-            return False
         from ..ivf_index import IVFFlatIndex
 
         lists = index_io.read_ivfflat_lists(self.index_path)
         nprobe = max(1, int(getattr(self.settings, "faiss_nprobe", 64)))
-        self._ivf = IVFFlatIndex(lists, device=resolve_gpu_device(self.settings), nprobe=nprobe)
+        device = resolve_gpu_device(self.settings)
+        rank, world = self._dist_rank_world()
+        # a sharded deployment: every rank keeps the centroids and its share of EVERY list (IVFFlatLists.shard), probes
+        # the same lists and the per-rank top-k lists are merged as in the flat mode (one all-gather per batch)
+        local = lists.shard(rank, world) if world > 1 else lists
+        self._ivf = IVFFlatIndex(local, device=device, nprobe=nprobe)
         self._ntotal = lists.ntotal
+        if world > 1:
+            from ..sharded import ShardedFlatIndex
+
+            self._sharded = ShardedFlatIndex(self._ivf, lists.metric, device=device, dim=int(lists.centroids.shape[1]),
+                                             max_batch=max(1, int(getattr(self.settings, "retrieval_batch_size", 32))))
         self._is_loaded = True
         logger.info("Set FAISS nprobe=%d", min(nprobe, lists.nlist))
-        logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (IVFFlat, %d lists)", lists.ntotal,
-                    lists.centroids.shape[1], lists.nlist)
+        logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (IVFFlat, %d lists; %d rows on this rank)",
+                    lists.ntotal, lists.centroids.shape[1], lists.nlist, local.ntotal)
         if lists.ntotal:
             self._ivf.search(np.zeros((1, lists.centroids.shape[1]), dtype=np.float32), 1)   # warm-up (:103-107)
         return True
@@ -171,7 +178,7 @@ class FAISSStore:
                 f"Embedding dimension mismatch: expected {self.settings.faiss_dim}, got {embeddings.shape[1]}")
         logger.debug("Searching FAISS index with %d queries, k=%d", embeddings.shape[0], k)
         try:
-            if self._ivf is not None:
+            if self._ivf is not None and self._sharded is None:
                 if isinstance(embeddings, DeviceEmbeddings):
                     if embeddings.device == self._ivf.device:   # the embedder's result never left HBM (as below)
                         res = self._ivf.search_from_device(embeddings.data_ptr, embeddings.shape[0], k, embeddings.stream)

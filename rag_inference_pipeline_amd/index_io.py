@@ -112,6 +112,22 @@ class IVFFlatLists:
     def ntotal(self) -> int:
         return int(self.rows.shape[0])
 
+    def shard(self, rank: int, world: int) -> "IVFFlatLists":
+        """Rank `rank`'s share of a corpus-sharded deployment: the same centroids and, of EVERY list, the contiguous
+        rows [len * rank / world, len * (rank + 1) / world) with their stored ids — the union of the ranks' candidates
+        for a probe set is the unsharded candidate set, so per-rank top-k lists merge to the unsharded result."""
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world {world}")
+        off = np.asarray(self.offsets, dtype=np.int64)
+        lens = np.diff(off)
+        lo = off[:-1] + lens * rank // world
+        hi = off[:-1] + lens * (rank + 1) // world
+        take = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)] or [np.zeros(0, np.int64)]).astype(np.int64)
+        new_off = np.zeros(len(off), dtype=np.int64)
+        np.cumsum(hi - lo, out=new_off[1:])
+        return IVFFlatLists(self.centroids, self.quantizer_metric, np.ascontiguousarray(self.rows[take]),
+                            np.ascontiguousarray(np.asarray(self.ids)[take]), new_off, self.metric, self.nprobe)
+
 
 def read_ivfflat_lists(path: str | os.PathLike) -> IVFFlatLists:
     """Parse a FAISS IndexIVFFlat file (fourcc `IwFl`) without flattening it.  Layout restated from upstream

@@ -19,7 +19,10 @@ def main() -> None:
 
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=index_path, faiss_dim=d))
+    extra = {}
+    if len(sys.argv) > 7:   # "nprobe:<n>": the IVFFlat nprobe mode, every rank holding its share of every list
+        extra = dict(RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=int(sys.argv[7].split(":")[1]))
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=index_path, faiss_dim=d, **extra))
     store.load()
     assert store.index_size > 0
     if rank == 0:

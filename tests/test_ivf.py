@@ -67,6 +67,31 @@ def test_oracle_is_nearest_lists_then_exact_topk(tmp_path, metric):
     np.testing.assert_array_equal(Da.view(np.uint32), Df.view(np.uint32))
 
 
+def test_list_shards_partition_every_list_and_merge_to_the_unsharded_result(tmp_path):
+    """A corpus-sharded deployment in the nprobe mode: rank r keeps the centroids and rows [len r / W, len (r + 1) / W) of
+    EVERY list (IVFFlatLists.shard).  The shards partition each list, and the oracle's per-shard top-k lists merged by
+    (score, ascending id) — what the device merge does with the all-gathered lists — are the unsharded oracle's result."""
+    X, path = _file(tmp_path, 4000, 16, 40, 1, seed=3)
+    lists = index_io.read_ivfflat_lists(path)
+    world = 3
+    shards = [lists.shard(r, world) for r in range(world)]
+    assert sum(s.ntotal for s in shards) == lists.ntotal
+    for l in range(lists.nlist):
+        want = lists.ids[lists.offsets[l]:lists.offsets[l + 1]]
+        got = np.concatenate([s.ids[s.offsets[l]:s.offsets[l + 1]] for s in shards])
+        np.testing.assert_array_equal(got, want)
+        assert max(s.offsets[l + 1] - s.offsets[l] for s in shards) - min(s.offsets[l + 1] - s.offsets[l] for s in shards) <= 1
+    Q = _unit(np.random.default_rng(8), 6, 16)
+    k, nprobe = 7, 5
+    Dw, Iw = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, 1)
+    parts = [oracle.ivf_search(s.centroids, s.quantizer_metric, s.rows, s.ids, s.offsets, Q, k, nprobe, 1) for s in shards]
+    D, I = oracle.merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), 1)
+    np.testing.assert_array_equal(I, Iw)
+    np.testing.assert_array_equal(D, Dw)
+    with pytest.raises(ValueError):
+        lists.shard(3, 3)
+
+
 def test_settings_carry_the_ivf_mode(monkeypatch):
     from rag_inference_pipeline_amd.config import PipelineSettings
     assert PipelineSettings().faiss_ivf_mode == "exhaustive"

@@ -227,6 +227,38 @@ def test_faiss_store_sharded_serving_mode(gpu_required, tmp_path):
 
 
 @pytest.mark.gpu
+def test_faiss_store_sharded_serving_in_the_ivf_nprobe_mode(gpu_required, tmp_path):
+    """RAG_AMD_IVF_MODE=nprobe under torch.distributed: every rank keeps the centroids and its share of EVERY inverted list,
+    probes the same lists, and rank 0's search() returns the unsharded nprobe result — the oracle's, bit for bit."""
+    from rag_inference_pipeline_amd import index_io
+    n, d, world, nlist, nprobe = 20_000, 96, 3, 128, 6
+    rng = np.random.default_rng(17)
+    X = rng.standard_normal((n, d), dtype=np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    path = tmp_path / "ivf_index.bin"
+    index_io.write_ivfflat_index(path, X, nlist, 1, seed=17, nprobe=nprobe, all_centroids=True)
+    lists = index_io.read_ivfflat_lists(path)
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"ivfstore{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_store_worker.py"), str(r), str(world), str(port), str(path), out, str(d),
+             f"nprobe:{nprobe}"],
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lead = np.load(outs[0])
+    for i, (nq, k) in enumerate([(1, 10), (32, 10), (5, 100)]):
+        D, I = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets,
+                                 oracle.synth_rows(4321 + i, 0, nq, d), k, nprobe, 1)
+        np.testing.assert_array_equal(lead[f"I{i}"], I)
+        np.testing.assert_array_equal(lead[f"D{i}"], D)
+    assert all(int(np.load(o)["served"]) == 3 for o in outs[1:])
+
+
+@pytest.mark.gpu
 def test_reranker_shards_batches_by_query(gpu_required, tmp_path):
     """SURVEY §8e, rerank row: with one process per GPU the rerank batch is split by query over the
     ranks that shard the index; order and scores (to fp32 rounding) equal the one-process result, and rerank requests
