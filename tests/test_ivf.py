@@ -203,3 +203,41 @@ def test_faiss_store_nprobe_mode_end_to_end(gpu_required, tmp_path):
     np.testing.assert_array_equal(Ie, If)
     assert (I != Ie).any()          # nprobe = 4 of 512 lists misses true neighbours: the two modes differ, as documented
     exhaustive.unload()
+
+
+@pytest.mark.gpu
+def test_hip_nprobe_search_at_the_generators_full_size(gpu_required):
+    """The generator's shape at full size (reference scripts/create_test_docs.py:12,83-104: 4.5M x 768, L2, nlist 4096,
+    nprobe 64) on a clustered corpus built on the GPU (scripts/bench_ivf.py: setup only): 32 + 1 queries against the
+    oracle — ids and fp32 score bits — and the size-independent properties: every result row lies in one of the query's
+    probed lists, distances ascend, a query that IS a corpus row finds it first at distance ~0."""
+    import argparse
+    import torch
+    import scripts.bench_ivf as bivf
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    if torch.cuda.mem_get_info()[1] < 100e9:
+        pytest.skip("needs an MI355X-class device (the 13.8 GB corpus is built on the GPU)")
+    n, d, nlist, nprobe, k = 4_500_000, 768, 4096, 64, 10
+    lists, cent = bivf.build_lists(n, d, nlist, nprobe, unit=True, clustered=True)
+    idx = IVFFlatIndex(lists, nprobe=nprobe)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q = bivf.draw((33, d), g, True).cpu().numpy()
+    Q[32] = lists.rows[1234567]
+    D, I = idx.search(Q, k)
+    idx.close()
+    bivf._CENTERS = None
+    del cent
+    torch.cuda.empty_cache()
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, 1)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    assert (np.diff(D, axis=1) >= 0).all() and (I >= 0).all()
+    assert I[32, 0] == lists.ids[1234567] and abs(D[32, 0]) < 1e-5
+    # membership: the list of every returned row is among the 64 lists nearest to the query
+    pos = np.empty(n, dtype=np.int64)
+    pos[lists.ids] = np.arange(n)
+    list_of = np.searchsorted(lists.offsets, pos[I], side="right") - 1
+    cn = (lists.centroids.astype(np.float64) ** 2).sum(1)
+    dist = cn[None, :] - 2.0 * Q.astype(np.float64) @ lists.centroids.astype(np.float64).T
+    kth = np.sort(dist, axis=1)[:, nprobe - 1]
+    assert (np.take_along_axis(dist, list_of, axis=1) <= kth[:, None] + 1e-6).all()
