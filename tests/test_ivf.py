@@ -144,6 +144,52 @@ def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlis
 
 
 @pytest.mark.gpu
+def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
+    """What rag_ivf_* refuses and what it answers at the edges: bad shapes, a closed handle, dimensions the mode does not
+    take, queries with no reachable row (-1 / FLT_MAX padding, as rag_index_search pads), non-finite queries (no results
+    under L2: every distance is inf or NaN), an empty batch."""
+    from rag_inference_pipeline_amd import _native
+    from rag_inference_pipeline_amd.index_io import IVFFlatLists
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    X, path = _file(tmp_path, 3000, 40, 30, 1, seed=9)
+    lists = index_io.read_ivfflat_lists(path)
+    idx = IVFFlatIndex(lists, nprobe=4)
+    Q = _unit(np.random.default_rng(1), 3, 40)
+    with pytest.raises(ValueError):
+        idx.search(Q[:, :8], 5)
+    for bad_k, bad_np in ((0, 4), (5, 0)):
+        with pytest.raises(_native.RagAmdError):
+            idx.search(Q, bad_k, nprobe=bad_np)
+    D, I = idx.search(Q[:0], 5)
+    assert D.shape == (0, 5) and I.shape == (0, 5)
+    # a query with a NaN / an overflowing norm: no results (ids -1, distances FLT_MAX), the others unaffected
+    Qb = Q.copy()
+    Qb[1, 3] = np.nan
+    Qb[2, :] = 3e19
+    D, I = idx.search(Qb, 5)
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Qb, 5, 4, 1)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    assert (I[1:] == -1).all() and (I[0] >= 0).all()
+    idx.close()
+    with pytest.raises(RuntimeError):
+        idx.search(Q, 5)
+    # only empty lists near the query: k results cannot be reached -> padding
+    cent = np.eye(4, 40, dtype=np.float32)
+    rows = np.tile(cent[3], (3, 1)).astype(np.float32)
+    sparse = IVFFlatLists(cent, 1, rows, np.array([7, 8, 9]), np.array([0, 0, 0, 0, 3]), 1, 1)
+    idx = IVFFlatIndex(sparse, nprobe=1)
+    D, I = idx.search(cent[:1], 4)           # nearest list (0) is empty
+    assert (I == -1).all() and (D == np.finfo(np.float32).max).all()
+    D, I = idx.search(cent[3:4], 4)          # list 3 holds three rows
+    assert sorted(I[0, :3].tolist()) == [7, 8, 9] and I[0, 3] == -1
+    idx.close()
+    with pytest.raises(_native.RagAmdError, match="1024"):
+        IVFFlatIndex(IVFFlatLists(np.zeros((2, 1032), np.float32), 1, np.zeros((0, 1032), np.float32), np.zeros(0, np.int64),
+                                  np.zeros(3, np.int64), 1, 1))
+
+
+@pytest.mark.gpu
 def test_hip_nprobe_search_on_device_pointers(gpu_required, tmp_path):
     """rag_ivf_search_device: queries and results in device memory, enqueued on the caller's stream — the same bits as
     the host-pointer entry point, batch after batch on one stream (the ticket counter is left at zero by every scan)."""
