@@ -14,6 +14,11 @@ struct rag_ivf {
     uint32_t* tile_off = nullptr;     // nlist + 1: first tile of each list
     hipStream_t stream = nullptr;     // the host-pointer entry point's stream
     std::mutex mu;
+    // the search workspace is shared by every stream searches are issued on: a search that follows one on a different
+    // stream first waits for ws_event (as rag_index does)
+    hipEvent_t ws_event = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
     // per-search workspace
     float* q_dev = nullptr; size_t q_cap = 0;
     float* qnorm = nullptr; size_t qn_cap = 0;
@@ -62,10 +67,12 @@ extern "C" int rag_ivf_create(int32_t d, int32_t metric, int32_t quantizer_metri
     h->coarse = coarse;
     h->n_cus = coarse->n_cus;
     DeviceGuard g(device);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ws_event, hipEventDisableTiming) != hipSuccess) {
+        if (h->stream) (void)hipStreamDestroy(h->stream);
         rag_index_destroy(coarse);
         delete h;
-        return fail(RAG_ERR_HIP, "hipStreamCreate failed");
+        return fail(RAG_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
     }
     *out = h;
     return RAG_OK;
@@ -82,6 +89,7 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (h->stream) (void)hipStreamDestroy(h->stream);
+        if (h->ws_event) (void)hipEventDestroy(h->ws_event);
     }
     rag_index_destroy(h->coarse);
     delete h;
@@ -184,6 +192,17 @@ int ivf_max_k(int d8) {
 // the whole search on `st`, device pointers
 int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe, float* out_s, long long* out_i, hipStream_t st) {
     using namespace ragk;
+    if (h->ws_used && h->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
+    struct Mark {  // record the workspace hand-over point on every exit path
+        rag_ivf* h;
+        hipStream_t st;
+        ~Mark() {
+            if (hipEventRecord(h->ws_event, st) == hipSuccess) {
+                h->ws_stream = st;
+                h->ws_used = true;
+            }
+        }
+    } mark{h, st};
     const int np = (int)std::min<long long>(nprobe, h->nlist);
     const int kmax = ivf_max_k(h->d8);
     const int grid = std::max(1, h->n_cus);

@@ -192,24 +192,27 @@ def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
 @pytest.mark.gpu
 def test_hip_nprobe_search_on_device_pointers(gpu_required, tmp_path):
     """rag_ivf_search_device: queries and results in device memory, enqueued on the caller's stream — the same bits as
-    the host-pointer entry point, batch after batch on one stream (the ticket counter is left at zero by every scan)."""
+    the host-pointer entry point, batch after batch without a host wait, alternating between two streams (the ticket counter
+    is left at zero by every scan; a search on another stream first waits for the previous one's hand-over event)."""
     import torch
     from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
     n, d, nlist, k = 30_000, 128, 512, 10
     X, path = _file(tmp_path, n, d, nlist, 1, seed=5)
     lists = index_io.read_ivfflat_lists(path)
     idx = IVFFlatIndex(lists, nprobe=16)
-    stream = torch.cuda.Stream()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]   # two callers: the handle's workspace is handed over by an event
     outs = []
-    with torch.cuda.stream(stream):
-        for rep, nq in enumerate((32, 1, 8, 32)):
+    for rep, nq in enumerate((32, 1, 8, 32, 32, 5)):
+        stream = streams[rep % 2]
+        with torch.cuda.stream(stream):
             Q = _unit(np.random.default_rng(100 + rep), nq, d)
             q = torch.from_numpy(Q).cuda()
             s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
             i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
             idx.search_device(q.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), stream.cuda_stream)
             outs.append((Q, q, s, i))
-    stream.synchronize()
+    for stream in streams:
+        stream.synchronize()
     for Q, _, s, i in outs:
         Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, 16, 1)
         np.testing.assert_array_equal(i.cpu().numpy(), Io)
