@@ -277,6 +277,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
         const int nb = std::min(kQT, nq - b0);
         // step 2: this pass's probe table -> list masks -> work items
         IvfPlanParams pp{h->probe + (size_t)b0 * np, h->tile_off, h->tiles, h->words, h->words + 32, nb, np, (int)h->nlist};
+        if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&ivf_plan_kernel), (size_t)h->nlist * sizeof(uint32_t)))) return rc;
         ivf_plan_kernel<<<dim3(1), dim3(1024), (size_t)h->nlist * sizeof(uint32_t), st>>>(pp);
         HIP_TRY(hipGetLastError());
         // step 3: the probed lists, each read once, against the pass's queries; step 4: merge of the workgroups' lists

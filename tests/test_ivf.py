@@ -190,6 +190,34 @@ def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
 
 
 @pytest.mark.gpu
+def test_hip_nprobe_search_with_the_most_lists_the_mode_takes(gpu_required):
+    """nlist = 32768 (the plan kernel's 128 KB of list masks in LDS): lists of a row or two, most of them one tile; one more
+    list is refused."""
+    from rag_inference_pipeline_amd import _native
+    from rag_inference_pipeline_amd.index_io import IVFFlatLists
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    rng = np.random.default_rng(41)
+    nlist, n, d = 32768, 50_000, 24
+    cent = _unit(rng, nlist, d)
+    rows = _unit(rng, n, d)
+    assign = np.sort(rng.integers(0, nlist, size=n))
+    offsets = np.zeros(nlist + 1, dtype=np.int64)
+    np.cumsum(np.bincount(assign, minlength=nlist), out=offsets[1:])
+    ids = rng.permutation(n).astype(np.int64)
+    lists = IVFFlatLists(cent, 1, rows, ids, offsets, 1, 64)
+    idx = IVFFlatIndex(lists)
+    Q = _unit(rng, 7, d)
+    for nprobe in (64, 300):
+        D, I = idx.search(Q, 10, nprobe=nprobe)
+        Do, Io = oracle.ivf_search(cent, 1, rows, ids, offsets, Q, 10, nprobe, 1)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    idx.close()
+    with pytest.raises(_native.RagAmdError, match="32768"):
+        IVFFlatIndex(IVFFlatLists(_unit(rng, nlist + 1, d), 1, rows[:1], ids[:1], np.r_[np.zeros(nlist + 1, np.int64), 1], 1, 1))
+
+
+@pytest.mark.gpu
 def test_hip_nprobe_search_on_device_pointers(gpu_required, tmp_path):
     """rag_ivf_search_device: queries and results in device memory, enqueued on the caller's stream — the same bits as
     the host-pointer entry point, batch after batch without a host wait, alternating between two streams (the ticket counter
