@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 7
+#define RAG_AMD_ABI_VERSION 8
 
 /* status codes */
 #define RAG_OK 0
@@ -276,6 +276,13 @@ int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_t nlist, co
                       const int64_t* ids_host, const int64_t* list_offsets_host);
 int64_t rag_ivf_ntotal(const rag_ivf* h);
 int64_t rag_ivf_nlist(const rag_ivf* h);
+/* Two-stage form of the list scan (as rag_index_set_screening for the flat search: a screening pass over a scaled fp16
+ * copy of the lists — half the bytes — then canonical fp32 scores of the candidates under a per-query certificate, the
+ * exact scan as the fallback; identical results).  On by default for k <= 100 when the corpus is inside the range the
+ * error bound covers (+50 % index memory); RAG_AMD_IVF_TWO_STAGE=0 at load or at search time turns it off.
+ * rag_ivf_two_stage: 1 when the copy exists and is valid.  rag_ivf_screen_stats: as rag_index_screen_stats. */
+int32_t rag_ivf_two_stage(const rag_ivf* h);
+int rag_ivf_screen_stats(rag_ivf* h, int64_t* queries, int64_t* fallbacks, double* max_err_ratio, int32_t reset);
 
 /* index.search(embeddings, k) with index.nprobe = nprobe (clamped to nlist).  Same output conventions as
  * rag_index_search (-1 / -+FLT_MAX padding when fewer than k rows are reachable).  Host pointers; blocks. */

@@ -233,6 +233,8 @@ def signatures() -> dict:
         "rag_ivf_set_lists": (C.c_int, [vp, f32p, C.c_int64, f32p, i64p, i64p]),
         "rag_ivf_ntotal": (C.c_int64, [vp]),
         "rag_ivf_nlist": (C.c_int64, [vp]),
+        "rag_ivf_two_stage": (C.c_int32, [vp]),
+        "rag_ivf_screen_stats": (C.c_int, [vp, i64p, i64p, C.POINTER(C.c_double), C.c_int32]),
         "rag_ivf_search": (C.c_int, [vp, f32p, C.c_int32, C.c_int32, C.c_int32, f32p, i64p]),
         "rag_ivf_search_device": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
         "rag_ivf_search_device_host_out": (C.c_int, [vp, vp, C.c_int32, C.c_int32, C.c_int32, f32p, i64p, vp]),

@@ -133,6 +133,13 @@ __device__ __forceinline__ f32x16 scan_step(const f32x4 x, const f32x4 q, f32x16
     }
 }
 
+// MAP mode of the scan kernel (the IVFFlat nprobe mode's screening pass, ivf_kernels.hip.h): the tiles to visit and, per
+// tile, which of the pass's queries may take candidates from it
+struct TileMapEntry {
+    uint32_t tile;    // tile number (rows 32 * tile ...)
+    uint32_t mask;    // bit q: query q may take candidates from this tile
+};
+
 struct ScanParams {
     const float* X;        // corpus, row-major, row_stride floats per row (zero padded to d8)
     const float* xnorm;    // canonical squared norms (L2 metric only)
@@ -176,6 +183,11 @@ struct ScanParams {
     int dyn_tile0;           // first tile of the dynamic region = n_full * grid * NW
     int n_dyn_groups;        // tickets [0, n_dyn_groups): whole NW-tile groups; then n_singles tickets of one tile each
     int n_singles;
+    // MAP == true only: the tile walk goes over map[0 .. *map_count) (entry v for wave v % NW of workgroup v / NW % grid,
+    // round-robin), candidates only for the queries in an entry's mask and never rows whose map_ids word is 0xFFFFFFFF
+    const TileMapEntry* map;
+    const uint32_t* map_count;
+    const uint32_t* map_ids;   // [rows] (padding rows of the list layout)
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
 #endif
@@ -201,7 +213,7 @@ __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = colum
 //        addressing is shared: the host passes row_stride and dc8 in 4-byte units).  Scores are
 //        approximate; instead of the best k the buffers keep every row within `margin` of the
 //        running k-th best, which is what makes the exact second stage a proof rather than a guess.
-template <int NW, int E, int D, bool L2, int P>
+template <int NW, int E, int D, bool L2, int P, bool MAP = false>
 __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) {
     // the screening prologue reduces ||q||^2 and max|q| through 2 * NW = 16 partials per query
     static_assert(P != 1 || NW == 8, "the screening pass (P == 1) is written for 8 waves per workgroup");
@@ -267,7 +279,25 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // The first ring loads go out in the middle of the prologue — after the query loads, before their LDS
     // stores.  Loads return in issue order: behind the ring's first touch of HBM (every CU at once) the
     // query fragments, all L2 hits, would wait for it; ahead of it they are stored while it is in flight.
-    int tile = tile_of(0);
+    // MAP: the walk goes over the tile map, round-robin (no tickets); an entry past the end is "no tile"
+    uint32_t map_n = 0u, qmask = 0xFFFFFFFFu;
+    int map_iters = 0;
+    auto map_entry = [&](int it) -> TileMapEntry {
+        const uint32_t v = (uint32_t)blockIdx.x * kScanWaves + wave + (uint32_t)it * tiles_per_iter;
+        TileMapEntry e{(uint32_t)p.n_tiles, 0u};
+        if (v < map_n) e = p.map[v];
+        return e;
+    };
+    int tile;
+    if constexpr (MAP) {
+        map_n = *p.map_count;
+        map_iters = (int)((map_n + (uint32_t)tiles_per_iter - 1u) / (uint32_t)tiles_per_iter);
+        const TileMapEntry e0 = map_entry(0);
+        tile = __builtin_amdgcn_readfirstlane((int)e0.tile);
+        qmask = __builtin_amdgcn_readfirstlane(e0.mask);
+    } else {
+        tile = tile_of(0);
+    }
     f32x4 xb[D];
     const float* pc = row_ptr(tile < p.n_tiles ? tile : p.n_tiles - 1);
     auto issue_ring = [&]() {
@@ -450,7 +480,8 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 
     const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
     // Warm start (k <= 16, 8-wave build, no sampled threshold): see the filter below.
-    const bool warm = kScanWaves == 8 && p.k <= 16 && !p.acc_out && p.thr_key == nullptr;
+    // (not in MAP mode: a list layout's padding rows — zero vectors, the best possible L2 score — would count as rows)
+    const bool warm = !MAP && kScanWaves == 8 && p.k <= 16 && !p.acc_out && p.thr_key == nullptr;
 
     // Overflow flags: pass number seq (one pass = one trip through the barrier loop below) owns
     // flag[seq & 3]; appends raise the flag of the pass that will check them, and pass seq clears
@@ -458,9 +489,11 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // still reading that pass's flag.
     uint32_t seq = 0;
     const bool dyn = p.dyn_ctr != nullptr;  // kernel-uniform; then n_iters == n_full: the static rounds
-    bool more = p.n_iters > 0;              // workgroup-uniform: iteration `it` exists
+    bool more = (MAP ? map_iters : p.n_iters) > 0;   // workgroup-uniform: iteration `it` exists
     for (int it = 0; more; ++it) {
         const bool active = tile < p.n_tiles;  // wave-uniform
+        TileMapEntry ent_n{(uint32_t)p.n_tiles, 0u};
+        if constexpr (MAP) ent_n = map_entry(it + 1);   // requested here, used behind the K loop
         if (dyn && it + 1 >= p.n_iters && tid == 0) {  // the ticket of iteration it + 1
             const uint32_t g = atomicAdd(p.dyn_ctr, 1u);
             tickw[0] = g;
@@ -508,7 +541,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         // the next tile: static rounds by formula, later ones by the ticket drawn at the top of this iteration
         int tnext = p.n_tiles;
         bool more_next;
-        if (!dyn || it + 1 < p.n_iters) {
+        if constexpr (MAP) {
+            more_next = it + 1 < map_iters;
+            tnext = __builtin_amdgcn_readfirstlane((int)ent_n.tile);
+        } else if (!dyn || it + 1 < p.n_iters) {
             more_next = it + 1 < p.n_iters;
             if (more_next) tnext = tile_of(it + 1);
         } else {
@@ -624,7 +660,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 
         // ---- filter + append
         uint32_t pending = 0;
-        if (active) {
+        if (active && (!MAP || ((qmask >> r) & 1u))) {
             float t = thr[r];
             float m = sc[0];
 #pragma unroll
@@ -633,7 +669,9 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (sc[i] >= t && row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil) {
+                    bool take = sc[i] >= t && row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil;
+                    if constexpr (MAP) take = take && p.map_ids[row] != 0xFFFFFFFFu;
+                    if (take) {
                         const uint32_t slot = atomicAdd(&cnt[r], 1u);
                         if (slot < (uint32_t)C) {
                             keys[(size_t)r * C + slot] = make_key(sc[i], (uint32_t)row);
@@ -756,6 +794,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         if (it == 0) RAGK_STAMP(2);
         tile = tnext;
         more = more_next;
+        if constexpr (MAP) qmask = __builtin_amdgcn_readfirstlane(ent_n.mask);
     }
 
     if (p.acc_out) return;
@@ -1168,6 +1207,7 @@ struct ResolveParams {
     float* out_s;            // [nq][k]
     long long* out_i;
     uint32_t* flag_out;      // null, or the caller's word (RAG_SEARCH_DEFER_FALLBACK): set to 1 when a certificate failed
+    const uint32_t* id_map;  // null, or [rows]: the id a row is ranked and reported by (the IVF list layout's stored ids)
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [nq][8] phase stamps
 #endif
@@ -1297,7 +1337,7 @@ __global__ __launch_bounds__(256) void screen_resolve_kernel(const ResolveParams
             }
             float score = acc + 0.0f;
             if (p.l2) score = __builtin_fmaf(2.0f, acc, -p.xnorm[my_row]) + 0.0f;
-            c_keys[g0 + lane] = make_key(score, my_row);
+            c_keys[g0 + lane] = make_key(score, p.id_map ? p.id_map[my_row] : my_row);
         }
     }
     __syncthreads();

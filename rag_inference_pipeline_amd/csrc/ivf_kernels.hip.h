@@ -33,10 +33,7 @@ constexpr int kIvfItemTiles = 8;                // tiles per work item = waves p
 constexpr int kIvfMaxLists = 32768;             // the plan kernel keeps one mask word per list in LDS
 constexpr int kIvfThrStride = 32;               // words between two queries' shared thresholds: a 128-byte line each
 
-struct IvfTile {      // 8 bytes: one wave's work in an item
-    uint32_t tile;    // global tile number (rows 32 * tile ...), kIvfNoTile = none
-    uint32_t mask;    // bit q: query q of the pass probes the tile's list
-};
+using IvfTile = TileMapEntry;   // 8 bytes, one wave's work in an item: {tile number, bit q = query q of the pass probes its list}
 constexpr uint32_t kIvfNoTile = 0xFFFFFFFFu;
 
 struct IvfPlanParams {
@@ -251,6 +248,8 @@ struct IvfBatchParams {
     uint32_t* done;            // workgroups that have left (same)
     u64* partial;              // out: [kQT][grid][k] keys, sorted descending per (query, workgroup)
     const u64* ceil;           // [kQT] or null: only keys strictly below ceil[q] are candidates (k > max_k rounds)
+    const uint32_t* enable;    // null, or a device word: unless it equals `epoch` the launch is a no-op (the two-stage
+    uint32_t epoch;            // search's fallback: flat_kernels.hip.h ScanParams.enable)
     uint32_t* gthr;            // [kQT * kIvfThrStride] thresholds shared by the workgroups (ord32 of a score, 0 = none
                                // yet; one 128-byte line per query): see the filter
     int d, d8, nq, k, l2;
@@ -266,6 +265,7 @@ template <int E, int D>
 __global__ __launch_bounds__(512) void ivf_batch_scan_kernel(const IvfBatchParams p) {
     constexpr int NW = kIvfItemTiles;
     constexpr int C = 64 * E;
+    if (p.enable && *p.enable != p.epoch) return;   // launch-uniform, before any ticket is drawn
     extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -85,6 +85,20 @@ ScanFn screen_fn_cap(int ring, bool l2) {
         return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 8, true, 1> : (ScanFn)ragk::scan_topk_kernel<8, E, 8, false, 1>;
     return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 4, true, 1> : (ScanFn)ragk::scan_topk_kernel<8, E, 4, false, 1>;
 }
+// the same pass over a tile map (MAP = true: the IVFFlat nprobe mode's screening pass, rag_ivf_host.hip.h)
+template <int E>
+ScanFn screen_map_fn_cap(int ring, bool l2) {
+    if (ring == 8)
+        return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 8, true, 1, true> : (ScanFn)ragk::scan_topk_kernel<8, E, 8, false, 1, true>;
+    return l2 ? (ScanFn)ragk::scan_topk_kernel<8, E, 4, true, 1, true> : (ScanFn)ragk::scan_topk_kernel<8, E, 4, false, 1, true>;
+}
+ScanFn screen_map_fn(int cap, int ring, bool l2) {
+    switch (cap) {
+        case 64: return screen_map_fn_cap<1>(ring, l2);
+        case 128: return screen_map_fn_cap<2>(ring, l2);
+        default: return screen_map_fn_cap<4>(ring, l2);
+    }
+}
 ScanFn screen_fn(int cap, int ring, bool l2) {
     switch (cap) {
         case 64: return screen_fn_cap<1>(ring, l2);
@@ -504,6 +518,8 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.flag_clear = nullptr;
         sp.dyn_ctr = sp.dyn_ctr_next = nullptr;
         sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
+        sp.map = nullptr;
+        sp.map_count = sp.map_ids = nullptr;
 #ifdef RAGK_STAMPS
         if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
         sp.stamps = enable ? nullptr : g_stamps;
@@ -669,6 +685,8 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.flag_clear = flag_clear ? flag_dev : nullptr;
     sp.dyn_ctr = sp.dyn_ctr_next = nullptr;
     sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
+    sp.map = nullptr;
+    sp.map_count = sp.map_ids = nullptr;
 #ifdef RAGK_STAMPS
     if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
     sp.stamps = g_stamps;
@@ -722,6 +740,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
         rp.out_s = os;
         rp.out_i = oi;
         rp.flag_out = flag_dev;
+        rp.id_map = nullptr;
 #ifdef RAGK_STAMPS
         rp.stamps = g_stamps ? g_stamps + 2048 * 4 : nullptr;  // second half of the stamp buffer
 #endif

@@ -8,8 +8,11 @@ struct rag_ivf {
     long long n = 0, nlist = 0;
     long long rows_padded = 0;        // every list rounded up to whole 32-row tiles
     rag_index* coarse = nullptr;      // flat index over the nlist centroids (the coarse quantizer)
-    float* X = nullptr;               // rows in padded list order, d8 columns
-    float* xnorm = nullptr;           // L2
+    rag_index* rowsidx = nullptr;     // the rows in padded list order as a flat index: it owns X / xnorm and, for the two-stage
+                                      // search, the scaled fp16 copy, its statistics and the certificate state
+    float* X = nullptr;               // = rowsidx->X: d8 columns
+    float* xnorm = nullptr;           // = rowsidx->xnorm (L2)
+    bool two_stage = false;           // the fp16 copy exists and covers the corpus (rag_index_set_screening on rowsidx)
     uint32_t* ids = nullptr;          // kIvfPadId on padding rows
     uint32_t* tile_off = nullptr;     // nlist + 1: first tile of each list
     hipStream_t stream = nullptr;     // the host-pointer entry point's stream
@@ -84,7 +87,7 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         DeviceGuard g(h->device);
         std::lock_guard<std::mutex> lk(h->mu);
         (void)hipDeviceSynchronize();
-        void* ptrs[] = {h->X, h->xnorm, h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->c_acc, h->tiles, h->words, h->partial,
+        void* ptrs[] = {h->ids, h->tile_off, h->q_dev, h->qnorm, h->c_scores, h->probe, h->c_acc, h->tiles, h->words, h->partial,
                         h->round_keys, h->out_s, h->out_i};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -92,10 +95,22 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);
     }
     rag_index_destroy(h->coarse);
+    rag_index_destroy(h->rowsidx);   // X, xnorm, the fp16 copy
     delete h;
     return RAG_OK;
 }
 
+extern "C" int32_t rag_ivf_two_stage(const rag_ivf* h) { return h && h->two_stage ? 1 : 0; }
+extern "C" int rag_ivf_screen_stats(rag_ivf* h, int64_t* queries, int64_t* fallbacks, double* max_err_ratio, int32_t reset) {
+    if (!h) return fail(RAG_ERR_INVALID_ARG, "null index handle");
+    if (!h->rowsidx) {
+        if (queries) *queries = 0;
+        if (fallbacks) *fallbacks = 0;
+        if (max_err_ratio) *max_err_ratio = 0.0;
+        return RAG_OK;
+    }
+    return rag_index_screen_stats(h->rowsidx, queries, fallbacks, max_err_ratio, reset);
+}
 extern "C" int64_t rag_ivf_ntotal(const rag_ivf* h) { return h ? h->n : 0; }
 extern "C" int64_t rag_ivf_nlist(const rag_ivf* h) { return h ? h->nlist : 0; }
 
@@ -132,24 +147,37 @@ extern "C" int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_
     if ((rc = dev_alloc(&h->words, (size_t)32 + ragk::kQT * ragk::kIvfThrStride))) return rc;
     HIP_TRY(hipMemsetAsync(h->words, 0, (32 + ragk::kQT * ragk::kIvfThrStride) * sizeof(uint32_t), st));
     if (rows_padded > 0) {
-        if ((rc = dev_alloc(&h->X, (size_t)rows_padded * h->d8))) return rc;
         if ((rc = dev_alloc(&h->ids, (size_t)rows_padded))) return rc;
-        HIP_TRY(hipMemsetAsync(h->X, 0, (size_t)rows_padded * h->d8 * sizeof(float), st));
         std::vector<uint32_t> ids32((size_t)rows_padded, kIvfPadId);
         for (int64_t l = 0; l < nlist; ++l) {
             const long long r0 = list_offsets_host[l], len = list_offsets_host[l + 1] - r0;
-            if (len == 0) continue;
             const long long dst = (long long)toff[(size_t)l] * kTileRows;
             for (long long i = 0; i < len; ++i) ids32[(size_t)(dst + i)] = (uint32_t)ids_host[r0 + i];
-            HIP_TRY(hipMemcpy2DAsync(h->X + dst * h->d8, (size_t)h->d8 * sizeof(float), rows_host + r0 * h->d, (size_t)h->d * sizeof(float),
-                                     (size_t)h->d * sizeof(float), (size_t)len, hipMemcpyHostToDevice, st));
         }
         HIP_TRY(hipMemcpyAsync(h->ids, ids32.data(), (size_t)rows_padded * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));   // ids32 leaves scope
-        if (h->metric == RAG_METRIC_L2) {
-            if ((rc = dev_alloc(&h->xnorm, (size_t)rows_padded))) return rc;
-            row_sqnorm_kernel<<<dim3((unsigned)((rows_padded + 255) / 256)), dim3(256), 0, st>>>(h->X, h->d8, h->d, 0, rows_padded, h->xnorm);
-            HIP_TRY(hipGetLastError());
+    }
+    // the rows, list after list with zero rows up to the next tile boundary, as a flat index of their own
+    rag_index* R = nullptr;
+    if ((rc = rag_index_create(h->d, h->metric, h->device, &R))) return rc;
+    h->rowsidx = R;
+    if (rows_padded > 0) {
+        if ((rc = rag_index_reserve(R, rows_padded))) return rc;
+        const std::vector<float> zeros((size_t)(kTileRows - 1) * h->d, 0.f);
+        for (int64_t l = 0; l < nlist; ++l) {
+            const long long r0 = list_offsets_host[l], len = list_offsets_host[l + 1] - r0;
+            if (len == 0) continue;
+            if ((rc = rag_index_add(R, rows_host + r0 * h->d, len))) return rc;
+            const long long pad = (kTileRows - len % kTileRows) % kTileRows;
+            if (pad && (rc = rag_index_add(R, zeros.data(), pad))) return rc;
+        }
+        if (R->n != rows_padded) return fail(RAG_ERR_STATE, "list layout: %lld rows placed, %lld expected", (long long)R->n, rows_padded);
+        h->X = R->X;
+        h->xnorm = R->xnorm;
+        // the two-stage search (fp16 screening pass + exact second stage): on unless RAG_AMD_IVF_TWO_STAGE=0 or the
+        // corpus is outside what it covers; never a reason not to serve
+        if (env_int("RAG_AMD_IVF_TWO_STAGE", 1) != 0 && round_up(h->d, 64) <= kScreenMaxD64) {
+            if (rag_index_set_screening(R, RAG_SCREEN_FP16) == RAG_OK) h->two_stage = R->screen_on && R->screen_valid;
         }
     }
     HIP_TRY(hipStreamSynchronize(st));
@@ -215,7 +243,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
         if ((rc = ivf_grow(&h->probe, &h->probe_cap, (size_t)nq * np))) return rc;
     }
     if ((rc = ivf_grow(&h->tiles, &h->tiles_cap, (size_t)(h->rows_padded / kTileRows + 1)))) return rc;
-    if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)kQT * grid * std::min(k, kmax)))) return rc;
+    if ((rc = ivf_grow(&h->partial, &h->partial_cap, (size_t)kQT * grid * std::max(std::min(k, kmax), 256)))) return rc;
     if (k > kmax && !h->round_keys && (rc = dev_alloc(&h->round_keys, (size_t)2 * kQT))) return rc;
     const bool l2 = h->metric == RAG_METRIC_L2;
     const bool cl2 = h->coarse->metric == RAG_METRIC_L2;
@@ -271,6 +299,9 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
         if (rc) return rc;
     }
     const bool share_thr = env_int("RAG_AMD_IVF_SHARED_THRESHOLDS", 1) != 0;   // (experiment switch; results do not depend on it)
+    // two-stage when the fp16 copy is valid and k is inside what the screening pass and ONE exact fallback round cover
+    const bool two_stage = h->two_stage && h->rows_padded > 0 && k <= kScreenMaxK && k <= kmax && h->d8 <= 1024 &&
+                           screen_capacity(h->rowsidx->d64, k) > 0 && env_int("RAG_AMD_IVF_TWO_STAGE", 1) != 0;
     const int S = h->d8 / 8;
     const int ring = S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 1);
     for (int b0 = 0; b0 < nq; b0 += kQT) {
@@ -280,7 +311,86 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
         if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(&ivf_plan_kernel), (size_t)h->nlist * sizeof(uint32_t)))) return rc;
         ivf_plan_kernel<<<dim3(1), dim3(1024), (size_t)h->nlist * sizeof(uint32_t), st>>>(pp);
         HIP_TRY(hipGetLastError());
-        // step 3: the probed lists, each read once, against the pass's queries; step 4: merge of the workgroups' lists
+        // step 3: the probed lists, each read once, against the pass's queries; step 4: merge of the workgroups' lists.
+        // Two-stage form (k <= 100, the fp16 copy valid): the flat search's screening pass over the tile map — half the bytes —
+        // then its resolve kernel (canonical fp32 scores of the band, certificate, results ranked by stored id), then the
+        // exact scan below as the fallback: a no-op unless a certificate failed, and then only those queries are rewritten
+        const uint32_t* fb_enable = nullptr;
+        const uint32_t* fb_qmask = nullptr;
+        uint32_t fb_epoch = 0;
+        if (two_stage) {
+            rag_index* R = h->rowsidx;
+            const int kp = 240;
+            const int cap = screen_capacity(R->d64, k);
+            const int kout = std::min(kp, cap);
+            if (++R->screen_epoch == 0) R->screen_epoch = 1;
+            const uint32_t epoch = R->screen_epoch;
+            ScanParams sp{};
+            sp.X = reinterpret_cast<const float*>(R->X16);
+            sp.xnorm = R->xnorm;
+            sp.qnorm = h->qnorm + b0;
+            sp.Q = q_dev + (size_t)b0 * h->d;
+            sp.partial = h->partial;
+            sp.dc8 = R->d64 / 2;
+            sp.n_rows = h->rows_padded;
+            sp.row_stride = R->d64 / 2;
+            sp.d = h->d;
+            sp.d8 = h->d8;
+            sp.nq = nb;
+            sp.k = k;
+            sp.n_tiles = (int)(h->rows_padded / kTileRows);
+            sp.epoch = epoch;
+            sp.tile_step = 1;
+            sp.kout = kout;
+            sp.x_absmax = R->x_absmax;
+            sp.x_normmax = R->x_normmax;
+            sp.x_scale = R->x_scale;
+            sp.margin_out = R->sq->margin;
+            sp.lossy = R->sq->lossy;
+            sp.wg_lossy = R->wg_lossy;
+            sp.map = h->tiles;
+            sp.map_count = h->words;
+            sp.map_ids = h->ids;
+            const int S16 = R->d64 / 16;
+            ScanFn fn = screen_map_fn(cap, S16 % 8 == 0 ? 8 : 4, l2);
+            const size_t lds = scan_lds_bytes(R->d64 / 2, cap);
+            if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
+            HIP_TRY(hipGetLastError());
+            ResolveParams rp{};
+            rp.src = KeyListSrc{h->partial, grid, kout};
+            rp.n_lists = grid;
+            rp.k = k;
+            rp.kp = kp;
+            rp.look = merge_look(grid, kout, k);
+            rp.X = R->X;
+            rp.row_stride = R->d8;
+            rp.xnorm = R->xnorm;
+            rp.Q = q_dev + (size_t)b0 * h->d;
+            rp.d = h->d;
+            rp.d8 = h->d8;
+            rp.l2 = l2 ? 1 : 0;
+            rp.qnorm = h->qnorm + b0;
+            rp.id_offset = 0;
+            rp.qs = R->sq;
+            rp.wg_lossy = R->wg_lossy;
+            rp.epoch = epoch;
+            rp.ctr = R->sctr;
+            rp.out_s = out_s + (size_t)b0 * k;
+            rp.out_i = out_i + (size_t)b0 * k;
+            rp.flag_out = nullptr;
+            rp.id_map = h->ids;
+            const size_t rlds = resolve_lds_bytes(h->d8, grid, rp.look, kp);
+            using ResolveFn = void (*)(const ResolveParams);
+            ResolveFn resolve = grid <= 256 ? (ResolveFn)screen_resolve_kernel<4, 1, 8>
+                                            : (grid <= 512 ? (ResolveFn)screen_resolve_kernel<2, 4, 8> : (ResolveFn)screen_resolve_kernel<kMergeMaxOwned, 4, 8>);
+            if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(resolve), rlds))) return rc;
+            hipLaunchKernelGGL(resolve, dim3(nb), dim3(256), rlds, st, rp);
+            HIP_TRY(hipGetLastError());
+            fb_enable = &R->sq->any_fallback;
+            fb_qmask = R->sq->fallback;
+            fb_epoch = epoch;
+        }
         int done = 0, flip = 0;
         while (done < k) {
             const int kr = std::min(kmax, k - done);
@@ -288,7 +398,8 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             const u64* ceil = done ? h->round_keys + (size_t)flip * kQT : nullptr;
             u64* last = k > kmax ? h->round_keys + (size_t)(flip ^ 1) * kQT : nullptr;
             IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_dev + (size_t)b0 * h->d, h->qnorm + b0, h->tiles, h->words, h->words + 1,
-                              h->words + 2, h->partial, ceil, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr, l2 ? 1 : 0};
+                              h->words + 2, h->partial, ceil, fb_enable, fb_epoch, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr,
+                              l2 ? 1 : 0};
             if (done) HIP_TRY(hipMemsetAsync(h->words + 32, 0, kQT * kIvfThrStride * sizeof(uint32_t), st));   // a round's thresholds bind that round's candidates only
             IvfScanFn fn = ivf_scan_fn(cap, ring);
             const size_t lds = ivf_scan_lds_bytes(h->d8, cap);
@@ -296,7 +407,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
             HIP_TRY(hipGetLastError());
             KeyListSrc src{h->partial, grid, kr};
-            MergeOut mo{out_s + (size_t)b0 * k + done, out_i + (size_t)b0 * k + done, last, k, h->qnorm + b0, 0, h->metric, 0, nullptr, 0};
+            MergeOut mo{out_s + (size_t)b0 * k + done, out_i + (size_t)b0 * k + done, last, k, h->qnorm + b0, 0, h->metric, 0, fb_qmask, fb_epoch};
             launch_merge(src, grid, nb, kr, merge_look(grid, kr, kr), mo, st);
             HIP_TRY(hipGetLastError());
             done += kr;

@@ -56,6 +56,16 @@ class IVFFlatIndex:
         return int(self._lib.rag_ivf_ntotal(self._h)) if self._h else 0
 
     @property
+    def two_stage(self) -> bool:
+        """True when searches with k <= 100 go through the fp16 screening pass + exact second stage (identical results)."""
+        return bool(self._h) and bool(self._lib.rag_ivf_two_stage(self._h))
+
+    def screen_stats(self, reset: bool = False) -> dict:
+        q, f, r = C.c_int64(0), C.c_int64(0), C.c_double(0.0)
+        _native.check(self._lib.rag_ivf_screen_stats(self._h, C.byref(q), C.byref(f), C.byref(r), 1 if reset else 0))
+        return {"queries": int(q.value), "fallbacks": int(f.value), "max_err_ratio": float(r.value)}
+
+    @property
     def nlist(self) -> int:
         return int(self._lib.rag_ivf_nlist(self._h)) if self._h else 0
 

@@ -144,6 +144,56 @@ def test_hip_nprobe_search_matches_the_oracle(gpu_required, tmp_path, n, d, nlis
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric", [1, 0])
+def test_two_stage_list_scan_is_identical_and_certified(gpu_required, tmp_path, monkeypatch, metric):
+    """The two-stage form (fp16 screening pass over the tile map -> canonical fp32 scores of the band -> certificate, exact
+    scan as the fallback) is what k <= 100 searches run by default: same ids and score bits as the one-stage scan
+    (RAG_AMD_IVF_TWO_STAGE=0) and the oracle; random data passes its certificates; 400 near-identical rows at the top of
+    a query's ranking cannot be certified and are answered by the exact fallback — only that query; duplicates rank by
+    ascending stored id."""
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    rng = np.random.default_rng(31)
+    n, d, nlist = 60_000, 384, 96
+    X = _unit(rng, n, d)
+    centre = _unit(rng, 1, d)[0]
+    clones = centre[None, :] + 1e-6 * rng.standard_normal((400, d)).astype(np.float32)
+    clones /= np.linalg.norm(clones, axis=1, keepdims=True)
+    X[rng.choice(n, size=400, replace=False)] = clones.astype(np.float32)
+    X[[5, 77, 4000, 19_999]] = X[123]
+    path = tmp_path / "two_stage.index"
+    index_io.write_ivfflat_index(path, X, nlist, metric, seed=31, nprobe=8, all_centroids=True)
+    lists = index_io.read_ivfflat_lists(path)
+    idx = IVFFlatIndex(lists, nprobe=8)
+    assert idx.two_stage
+    Q = np.vstack([_unit(rng, 30, d), X[[123]], centre[None, :]]).astype(np.float32)
+    for k, nprobe in ((10, 8), (100, 8), (10, 1), (48, 20)):
+        idx.screen_stats(reset=True)
+        D, I = idx.search(Q, k, nprobe=nprobe)
+        st = idx.screen_stats()
+        Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, metric)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+        assert st["queries"] == len(Q) and 1 <= st["fallbacks"] <= 3 and st["max_err_ratio"] < 0.5, st
+        monkeypatch.setenv("RAG_AMD_IVF_TWO_STAGE", "0")
+        D1, I1 = idx.search(Q, k, nprobe=nprobe)
+        monkeypatch.delenv("RAG_AMD_IVF_TWO_STAGE")
+        assert idx.screen_stats()["queries"] == len(Q)          # the one-stage search certifies nothing
+        np.testing.assert_array_equal(I, I1)
+        np.testing.assert_array_equal(D.view(np.uint32), D1.view(np.uint32))
+    D, I = idx.search(X[[123]], 8, nprobe=nlist)
+    assert I[0, :5].tolist() == [5, 77, 123, 4000, 19_999]
+    idx.close()
+    monkeypatch.setenv("RAG_AMD_IVF_TWO_STAGE", "0")     # at load: no fp16 copy at all
+    plain = IVFFlatIndex(lists, nprobe=8)
+    monkeypatch.delenv("RAG_AMD_IVF_TWO_STAGE")
+    assert not plain.two_stage
+    D2, I2 = plain.search(Q, 10)
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, 10, 8, metric)
+    np.testing.assert_array_equal(I2, Io)
+    plain.close()
+
+
+@pytest.mark.gpu
 def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
     """What rag_ivf_* refuses and what it answers at the edges: bad shapes, a closed handle, dimensions the mode does not
     take, queries with no reachable row (-1 / FLT_MAX padding, as rag_index_search pads), non-finite queries (no results
