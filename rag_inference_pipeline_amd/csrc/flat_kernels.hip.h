@@ -188,6 +188,8 @@ struct ScanParams {
     const TileMapEntry* map;
     const uint32_t* map_count;
     const uint32_t* map_ids;   // [rows] (padding rows of the list layout)
+    uint32_t* map_thr;         // null, or [kQT * 32] band edges shared by the workgroups (ord32, 0 = none; a 128-byte line per
+                               // query): see "shared band edges" in the kernel
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
 #endif
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // stores.  Loads return in issue order: behind the ring's first touch of HBM (every CU at once) the
     // query fragments, all L2 hits, would wait for it; ahead of it they are stored while it is in flight.
     // MAP: the walk goes over the tile map, round-robin (no tickets); an entry past the end is "no tile"
-    uint32_t map_n = 0u, qmask = 0xFFFFFFFFu;
+    uint32_t map_n = 0u, qmask = 0xFFFFFFFFu, map_seen = 0u;
     int map_iters = 0;
     auto map_entry = [&](int it) -> TileMapEntry {
         const uint32_t v = (uint32_t)blockIdx.x * kScanWaves + wave + (uint32_t)it * tiles_per_iter;
@@ -493,7 +495,21 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     for (int it = 0; more; ++it) {
         const bool active = tile < p.n_tiles;  // wave-uniform
         TileMapEntry ent_n{(uint32_t)p.n_tiles, 0u};
-        if constexpr (MAP) ent_n = map_entry(it + 1);   // requested here, used behind the K loop
+        if constexpr (MAP) {
+            ent_n = map_entry(it + 1);   // requested here, used behind the K loop
+            // Shared band edges.  A workgroup meets a given query in one or two of its items, so a filter that learns only
+            // from its own rows stays cold (sort after sort).  The lower edge of a band — a k-th best approximate score
+            // minus the margin — established by ANY workgroup bounds the final band from below (that workgroup's k-th
+            // best is at most the global one), so it is published (atomic max, one line per query) and wave 0 refreshes
+            // the local filters from the published values once per iteration, the load consumed an iteration later.
+            if (P == 1 && p.map_thr && wave == 0 && lane < kQT) {
+                if (map_seen) {
+                    const float tg = unord32(map_seen);
+                    if (tg > thr[lane]) thr[lane] = tg;   // parked (+inf) and NaN filters stay
+                }
+                map_seen = __hip_atomic_load(p.map_thr + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (dyn && it + 1 >= p.n_iters && tid == 0) {  // the ticket of iteration it + 1
             const uint32_t g = atomicAdd(p.dyn_ctr, 1u);
             tickw[0] = g;
@@ -724,6 +740,10 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                             // every kept key already passed it, and a query sorted along with the others
                             // before it holds k rows must not fall back to an open filter
                             float tnew = full ? fmaxf(kscore - mrg[q], thr[q]) : thr[q];
+                            if constexpr (MAP) {   // publish a band edge (never one without its margin: -0.0f marks a given-up band)
+                                if (full && lane == 0 && p.map_thr && !__builtin_signbit(mrg[q]) && kscore - mrg[q] > thr[q])
+                                    atomicMax(p.map_thr + q * 32, ord32(kscore - mrg[q]));
+                            }
                             uint32_t keep = 0;
 #pragma unroll
                             for (int e = 0; e < E; ++e) {
@@ -741,7 +761,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
                                 // voiding the query for that sent 19 of 32 ordinary queries to the fallback on a
                                 // corpus with 400 copies of one row.)
                                 if (lane == 0) {
-                                    mrg[q] = 0.f;
+                                    mrg[q] = MAP ? -0.0f : 0.f;   // (the same arithmetic; MAP: "this band was given up")
                                     if (p.wg_lossy) p.wg_lossy[(size_t)q * gridDim.x + blockIdx.x] = p.epoch;
                                 }
                                 tnew = kscore;  // keep > C - 16 >= k implies full

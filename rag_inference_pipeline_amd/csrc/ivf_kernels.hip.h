@@ -41,7 +41,7 @@ struct IvfPlanParams {
     const uint32_t* tile_off;   // [nlist + 1] first tile of each list (padded layout)
     IvfTile* tiles;             // out: the probed lists' tiles, packed ([<= all tiles])
     uint32_t* n_tiles;          // out
-    uint32_t* gthr;             // [kQT * kIvfThrStride] the scan's shared thresholds: zeroed here
+    uint32_t* gthr;             // [2 * kQT * kIvfThrStride] the scans' shared thresholds / band edges: zeroed here
     int nq, nprobe, nlist;
 };
 
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(1024) void ivf_plan_kernel(const IvfPlanParams p) {
         base_s = 0u;
         n_big = 0u;
     }
-    if (t < kQT) p.gthr[t * kIvfThrStride] = 0u;
+    if (t < 2 * kQT) p.gthr[t * kIvfThrStride] = 0u;   // the exact scan's thresholds and the screening pass's band edges
     __syncthreads();
     const int np = p.nq * p.nprobe;
     for (int i = t; i < np; i += 1024) {

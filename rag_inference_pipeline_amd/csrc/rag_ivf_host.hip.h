@@ -144,8 +144,8 @@ extern "C" int rag_ivf_set_lists(rag_ivf* h, const float* centroids_host, int64_
     hipStream_t st = h->stream;
     if ((rc = dev_alloc(&h->tile_off, (size_t)nlist + 1))) return rc;
     HIP_TRY(hipMemcpyAsync(h->tile_off, toff.data(), ((size_t)nlist + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    if ((rc = dev_alloc(&h->words, (size_t)32 + ragk::kQT * ragk::kIvfThrStride))) return rc;
-    HIP_TRY(hipMemsetAsync(h->words, 0, (32 + ragk::kQT * ragk::kIvfThrStride) * sizeof(uint32_t), st));
+    if ((rc = dev_alloc(&h->words, (size_t)32 + 2 * ragk::kQT * ragk::kIvfThrStride))) return rc;
+    HIP_TRY(hipMemsetAsync(h->words, 0, (32 + 2 * ragk::kQT * ragk::kIvfThrStride) * sizeof(uint32_t), st));
     if (rows_padded > 0) {
         if ((rc = dev_alloc(&h->ids, (size_t)rows_padded))) return rc;
         std::vector<uint32_t> ids32((size_t)rows_padded, kIvfPadId);
@@ -351,6 +351,7 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             sp.map = h->tiles;
             sp.map_count = h->words;
             sp.map_ids = h->ids;
+            sp.map_thr = share_thr ? h->words + 32 + kQT * kIvfThrStride : nullptr;
             const int S16 = R->d64 / 16;
             ScanFn fn = screen_map_fn(cap, S16 % 8 == 0 ? 8 : 4, l2);
             const size_t lds = scan_lds_bytes(R->d64 / 2, cap);
