@@ -637,12 +637,15 @@ def main() -> None:
             clustered = bivf.run(argparse.Namespace(**base, batches="1,32", clustered=True))
             generator = bivf.run(argparse.Namespace(**base, batches="32", clustered=False))
             b32 = clustered["batches"]["32"]
-            ach = b32["union_bytes"] / b32["ms_per_batch"] / 1e6
+            ach = b32["scan_bytes"] / b32["ms_per_batch"] / 1e6
             ivf_leg = {"clustered_balanced_lists": clustered, "generator_gaussian_rows": generator,
-                       "roofline": {"bound": "hbm", "kernel": "ivf_batch_scan_kernel (whole search timed: coarse quantizer, plan, "
-                                    "list scan, merge)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_batch": b32["union_bytes"],
-                                    "workload": "clustered, batch 32", "kernel_only_source": "profiles/r04_ivf_nprobe.json"},
+                       "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel<P=1, MAP> fp16 screening pass over the probed lists (whole search timed: coarse "
+                                    "quantizer, plan, screening pass, resolve, self-disabling exact fallback)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_batch": b32["scan_bytes"],
+                                    "bytes_basis": "rows of the union of the batch's probed lists, each once, in the fp16 copy the "
+                                                   "two-stage search screens (2 B x d64 per row); the same rows in fp32: union_bytes",
+                                    "workload": "clustered, batch 32, two-stage search (the default for k <= 100)",
+                                    "kernel_only_source": "profiles/r04_ivf_nprobe.json"},
                        "note": "generator_gaussian_rows: iid Gaussian rows have no cluster structure — k-means on 10 000 of "
                                "them leaves most lists empty and a few huge, every query's 64 lists hold nearly the whole corpus "
                                "and the mode costs what the exhaustive scan costs; clustered: rows from a mixture of 4096 "

@@ -9,7 +9,8 @@ with one matmul per chunk, grouped by list) and handed to rag_ivf_set_lists thro
 Timed: rag_ivf_search_device on one stream, queries resident in HBM, HIP events around `steps` batches of DIFFERENT
 queries (eight query sets in rotation).  Prints one JSON object:
   per batch size  ms per batch, queries/s, algorithmic bytes (rows of the UNION of the batch's probed lists x d x 4:
-                  what a search that reads every probed list once must move), GB/s of the whole search against them,
+                  what a search that reads every probed list once must move; `scan_bytes`: the same rows in the fp16
+                  copy the two-stage search screens, d rounded up to 64), GB/s of the whole search against them,
                   and the bytes a per-(query, list) scan would read (rows counted once per probing query);
   with --exhaustive the flat search of the same rows beside it (what RAG_AMD_IVF_MODE=exhaustive costs).
 """
@@ -118,12 +119,17 @@ def run(a) -> dict:
         ms = e0.elapsed_time(e1) / a.steps
         ub = float(np.mean([union_rows[st % 8] for st in range(a.steps)])) * a.d * 4
         pb = float(np.mean([pair_rows[st % 8] for st in range(a.steps)])) * a.d * 4
+        # what the list scan reads: the fp32 rows, or — two-stage search, k <= 100 — their fp16 copy (d rounded up to 64)
+        two = bool(idx.two_stage) and a.k <= 100
+        rb = ub / (a.d * 4) * ((a.d + 63) // 64 * 64) * 2 if two else ub
         out["batches"][str(nq)] = {"ms_per_batch": round(ms, 4), "queries_per_s": round(nq / ms * 1e3, 1),
-                                   "union_bytes": int(ub), "pair_bytes": int(pb),
+                                   "union_bytes": int(ub), "pair_bytes": int(pb), "two_stage": two, "scan_bytes": int(rb),
+                                   "search_gbps_vs_scan_bytes": round(rb / ms / 1e6, 1),
                                    "search_gbps_vs_union": round(ub / ms / 1e6, 1),
                                    "corpus_fraction_read": round(ub / (a.n * a.d * 4.0), 4),
                                    "id_checksum": int(i.sum().item())}
-        print(f"nq={nq}: {ms:.4f} ms/batch, union {ub / 1e9:.3f} GB -> {ub / ms / 1e6:.0f} GB/s (whole search)", file=sys.stderr)
+        print(f"nq={nq}: {ms:.4f} ms/batch, union {ub / 1e9:.3f} GB, scan reads {rb / 1e9:.3f} GB -> {rb / ms / 1e6:.0f} GB/s "
+              f"(whole search{', two-stage' if two else ''})", file=sys.stderr)
     if a.exhaustive:
         from rag_inference_pipeline_amd.flat_index import FlatIndex
         flat = FlatIndex(a.d, 1)

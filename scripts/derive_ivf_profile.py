@@ -21,9 +21,13 @@ def main() -> None:
     run = last_json(sys.argv[1])
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3  # us
-    names = ("query_sqnorm_kernel", "scan_topk_kernel", "ivf_coarse_select_kernel", "ivf_plan_kernel", "ivf_batch_scan_kernel",
-             "tournament_merge_kernel")
-    scans = [dur(r) for r in rows if "ivf_batch_scan_kernel" in r["Kernel_Name"]]
+    names = ("query_sqnorm_kernel", "0, false>(ragk::ScanParams)", "ivf_coarse_select_kernel", "ivf_plan_kernel",
+             "1, true>(ragk::ScanParams)", "screen_resolve_kernel", "ivf_batch_scan_kernel", "tournament_merge_kernel")
+    # the list scan: the exact kernel, or — two-stage search — the flat scan kernel's screening pass in MAP mode (its exact
+    # fallback launches are no-ops of a few microseconds)
+    two = any(b.get("two_stage") for b in run["batches"].values())
+    is_scan = (lambda nm: "scan_topk_kernel" in nm and "1, true>(" in nm) if two else (lambda nm: "ivf_batch_scan_kernel" in nm)
+    scans = [dur(r) for r in rows if is_scan(r["Kernel_Name"])]
     per_kernel = {n: [dur(r) for r in rows if n in r["Kernel_Name"]] for n in names}
     batches = list(run["batches"].items())
     total_passes = sum(-(-int(nq) // 32) for nq, _ in batches)
@@ -39,12 +43,17 @@ def main() -> None:
         scan_us = sum(mine) / len(mine) * passes
         out["batches"][nq] = {
             "whole_search_ms": b["ms_per_batch"], "whole_search_gbps_vs_union": b["search_gbps_vs_union"],
+            "two_stage": bool(b.get("two_stage")),
             "list_scan_kernel_us": round(scan_us, 1), "union_bytes": b["union_bytes"],
-            "list_scan_gbps": round(b["union_bytes"] / scan_us / 1e3, 1),
-            "list_scan_frac_of_hbm_peak": round(b["union_bytes"] / scan_us / 1e3 / 8000.0, 4),
+            "scan_bytes": b.get("scan_bytes", b["union_bytes"]),
+            "list_scan_gbps": round(b.get("scan_bytes", b["union_bytes"]) / scan_us / 1e3, 1),
+            "list_scan_frac_of_hbm_peak": round(b.get("scan_bytes", b["union_bytes"]) / scan_us / 1e3 / 8000.0, 4),
             "corpus_fraction_read": b["corpus_fraction_read"], "pair_bytes": b["pair_bytes"],
         }
-    out["kernels_avg_us_all_launches"] = {n: round(sum(v) / len(v), 1) for n, v in per_kernel.items() if v}
+    label = {"0, false>(ragk::ScanParams)": "scan_topk_kernel<P=0> (coarse quantizer, sums parked)",
+             "1, true>(ragk::ScanParams)": "scan_topk_kernel<P=1, MAP> (fp16 screening pass over the probed lists)",
+             "ivf_batch_scan_kernel": "ivf_batch_scan_kernel (exact list scan; a no-op fallback launch in the two-stage search)"}
+    out["kernels_avg_us_all_launches"] = {label.get(n, n): round(sum(v) / len(v), 1) for n, v in per_kernel.items() if v}
     for extra in sys.argv[3:]:
         e = last_json(extra)
         out.setdefault("other_runs", []).append({k: e[k] for k in ("workload", "list_rows", "batches") if k in e}
