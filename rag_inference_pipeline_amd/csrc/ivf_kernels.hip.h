@@ -20,6 +20,12 @@
 //     (threshold filter -> LDS candidate buffers -> wave bitonic sort on overflow); a workgroup emits its best k keys per
 //     query and the flat search's tournament merge ranks the workgroups' lists.
 //
+// The default search (k <= 100) is the TWO-STAGE form of this: the screening pass is the flat scan kernel itself, in its MAP
+// mode, over a scaled fp16 copy of the rows (flat_kernels.hip.h scan_topk_kernel<.., P = 1, MAP = true>: the plan's packed
+// entries as the tile walk, the masks, padding rows excluded), then screen_resolve_kernel (canonical fp32 scores of the
+// band, certificate, ranking by stored id); `ivf_batch_scan_kernel` below is then the self-disabling fallback — and the
+// whole search when k > 100 or RAG_AMD_IVF_TWO_STAGE=0 (rag_ivf_host.hip.h).
+//
 // Ranking is (score, ascending stored id) — faiss leaves ties to its heap's visiting order; the candidate SET (the union
 // of the probed lists) is what the mode is about.  With nprobe >= nlist the result equals rag_index_search's bit for bit.
 #pragma once
