@@ -5,6 +5,8 @@ index.nprobe (faiss_store.py:84-92): on that file the reference looks only at th
 faiss is absent here, so parity is unpinned as for the flat search; what is held: oracle == a literal float64 numpy
 restatement of "nearest lists, then exact top-k of their rows"; HIP == oracle (ids and fp32 score bits); nprobe = nlist
 == the exhaustive flat search."""
+import os
+
 import numpy as np
 import pytest
 
@@ -191,6 +193,69 @@ def test_two_stage_list_scan_is_identical_and_certified(gpu_required, tmp_path, 
     Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, 10, 8, metric)
     np.testing.assert_array_equal(I2, Io)
     plain.close()
+
+
+@pytest.mark.gpu
+def test_randomised_ivf_searches_match_the_oracle(gpu_required):
+    """30 seeded random draws of everything at once: dimension (ring depths 8 / 4 / 1, fp16 copies padded to 64), list count
+    and lengths (empty lists, lists of one tile, one dominant list), metric of the rows and of the quantizer, k (every buffer
+    size, above 100 -> one-stage, above one pass -> rounds), nprobe (all selection widths, > 256 -> the flat search as the
+    quantizer), query counts over several passes, and the data the certificate finds hard — tight clusters, exact duplicates,
+    coordinates on a coarse grid, a dominant coordinate.  Lists are ANY partition of the rows (the mode searches the lists it
+    is given); ids a random permutation.  Ids and fp32 score bits against the oracle every time."""
+    from rag_inference_pipeline_amd.index_io import IVFFlatLists
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    rng = np.random.default_rng(20261006)
+    dims = [8, 24, 64, 100, 200, 384, 520, 768, 1024]
+    fallbacks = queries = two_stage_runs = 0
+    for trial in range(int(os.environ.get("RAG_AMD_TEST_TRIALS", "30"))):
+        d = int(rng.choice(dims))
+        n = int(rng.integers(1, 15_000 if d <= 384 else 6_000))
+        nlist = int(rng.choice([1, 7, 64, 300, 2000]))
+        nq = int(rng.integers(1, 70))
+        k = int(rng.choice([1, 3, 10, 16, 17, 48, 49, 100, 130, 260]))
+        nprobe = int(rng.choice([1, 4, 64, 100, 200, 400]))
+        metric, qmetric = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        kind = trial % 5
+        if kind == 0:
+            X = rng.standard_normal((n, d), dtype=np.float32) * np.float32(rng.choice([1e-3, 1.0, 300.0]))
+        elif kind == 1:
+            centres = rng.standard_normal((max(1, n // 200), d), dtype=np.float32)
+            X = centres[rng.integers(0, len(centres), size=n)] + np.float32(1e-3) * rng.standard_normal((n, d), dtype=np.float32)
+        elif kind == 2:
+            X = rng.standard_normal((n, d), dtype=np.float32)
+            X[n // 2:] = X[: n - n // 2]
+        elif kind == 3:
+            X = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+        else:
+            X = rng.standard_normal((n, d), dtype=np.float32)
+            X[:, 0] *= 100.0
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        Q = rng.standard_normal((nq, d), dtype=np.float32)
+        if kind == 1:
+            Q = X[rng.integers(0, n, size=nq)] + np.float32(1e-2) * Q
+        Q = np.ascontiguousarray(Q, dtype=np.float32)
+        cent = np.ascontiguousarray(X[rng.integers(0, n, size=nlist)] + np.float32(0.1) * rng.standard_normal((nlist, d), dtype=np.float32))
+        weights = rng.random(nlist) ** (3 if trial % 2 else 1)       # every other draw: a few lists take most rows
+        assign = np.sort(rng.choice(nlist, size=n, p=weights / weights.sum()))
+        offsets = np.zeros(nlist + 1, dtype=np.int64)
+        np.cumsum(np.bincount(assign, minlength=nlist), out=offsets[1:])
+        ids = rng.permutation(n).astype(np.int64)
+        lists = IVFFlatLists(cent, qmetric, X, ids, offsets, metric, nprobe)
+        idx = IVFFlatIndex(lists)
+        D, I = idx.search(Q, k)
+        Do, Io = oracle.ivf_search(cent, qmetric, X, ids, offsets, Q, k, nprobe, metric)
+        msg = f"trial {trial}: kind={kind} n={n} d={d} nlist={nlist} nq={nq} k={k} nprobe={nprobe} metric={metric}/{qmetric}"
+        np.testing.assert_array_equal(I, Io, err_msg=msg)
+        np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32), err_msg=msg)
+        st = idx.screen_stats()
+        assert st["max_err_ratio"] < 1.0, msg
+        if idx.two_stage and k <= 100:
+            two_stage_runs += 1
+            fallbacks += st["fallbacks"]
+            queries += st["queries"]
+        idx.close()
+    assert two_stage_runs >= 10 and queries > 0 and 0 < fallbacks < queries
 
 
 @pytest.mark.gpu
