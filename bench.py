@@ -644,6 +644,9 @@ def main() -> None:
                                     "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_batch": b32["scan_bytes"],
                                     "bytes_basis": "rows of the union of the batch's probed lists, each once, in the fp16 copy the "
                                                    "two-stage search screens (2 B x d64 per row); the same rows in fp32: union_bytes",
+                                    "traffic": (_profile_json("r04_ivf_hbm_traffic.json") or {}).get("two_stage_screening_pass", {}).get("traffic_bytes_per_launch"),
+                                    "traffic_source": "profiles/r04_ivf_hbm_traffic.json: FETCH_SIZE x2 (gfx950 correction) of the screening "
+                                                      "pass from a separate rocprofv3 --pmc run of this workload; not collected inside this run",
                                     "workload": "clustered, batch 32, two-stage search (the default for k <= 100)",
                                     "kernel_only_source": "profiles/r04_ivf_nprobe.json"},
                        "note": "generator_gaussian_rows: iid Gaussian rows have no cluster structure — k-means on 10 000 of "
