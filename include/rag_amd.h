@@ -43,7 +43,7 @@ extern "C" {
 /* Bumped on EVERY change of a prototype, a struct layout or a constant below (rounds 1-3 forgot to: a library built from
  * an older header passed the loader's check).  The Python binding compares rag_abi_version() with THIS line, parsed from
  * the header it ships with, and rag_source_digest() with a digest of the csrc/ sources it ships with. */
-#define RAG_AMD_ABI_VERSION 8
+#define RAG_AMD_ABI_VERSION 9
 
 /* status codes */
 #define RAG_OK 0
@@ -355,6 +355,12 @@ int rag_index_search_gather_device(rag_index* h, rag_comm* c, const float* queri
                                    int32_t mode, void* pack_dev, void* gathered_dev, float* out_scores_dev,
                                    int64_t* out_ids_dev, uint32_t* any_flag_dev, void* host_mirror, void* stream,
                                    void* comm_stream);
+/* The same step for a rank of a sharded IVFFlat index in the nprobe mode (every rank holds its share of every list): the
+ * local search is rag_ivf_search_device(h, ..., nprobe, ...); its list is always final (the two-stage form resolves its
+ * fallback on the device), so the block's flag word is 0. */
+int rag_ivf_search_gather_device(rag_ivf* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                                 void* pack_dev, void* gathered_dev, float* out_scores_dev, int64_t* out_ids_dev,
+                                 uint32_t* any_flag_dev, void* host_mirror, void* stream, void* comm_stream);
 
 /* ---- BERT-family transformer: query encoder and cross-encoder ----------------------------- */
 

@@ -251,6 +251,8 @@ def signatures() -> dict:
         "rag_pack_layout": (C.c_int, [C.c_int32, C.c_int32, i64p, i64p, i64p]),
         "rag_index_search_gather_device": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp,
                                                      vp, vp]),
+        "rag_ivf_search_gather_device": (C.c_int, [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp,
+                                                   vp, vp]),
         "rag_bert_weight_count": (C.c_int32, [C.POINTER(BertConfigStruct)]),
         "rag_bert_create": (C.c_int, [C.POINTER(BertConfigStruct), C.POINTER(vp), C.c_int32, C.c_int32,
                                       C.POINTER(vp)]),

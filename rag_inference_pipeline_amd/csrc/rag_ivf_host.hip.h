@@ -475,3 +475,38 @@ extern "C" int rag_ivf_search_device_host_out(rag_ivf* h, const float* queries_d
     std::lock_guard<std::mutex> lk(h->mu);
     return ivf_search_to_host(h, queries_dev, nq, k, nprobe, out_scores, out_ids, (hipStream_t)stream);
 }
+
+extern "C" int rag_ivf_search_gather_device(rag_ivf* h, rag_comm* c, const float* queries_dev, int32_t nq, int32_t k, int32_t nprobe,
+                                            void* pack_dev, void* gathered_dev, float* out_scores_dev, int64_t* out_ids_dev,
+                                            uint32_t* any_flag_dev, void* host_mirror, void* stream, void* comm_stream) {
+    if (!c) return fail(RAG_ERR_INVALID_ARG, "null communicator");
+    if (nq <= 0) return fail(RAG_ERR_INVALID_ARG, "nq must be positive");
+    if (!pack_dev || !gathered_dev || !any_flag_dev) return fail(RAG_ERR_INVALID_ARG, "null pack / gather / flag buffer");
+    if (reinterpret_cast<uintptr_t>(pack_dev) % 8 || reinterpret_cast<uintptr_t>(gathered_dev) % 8)
+        return fail(RAG_ERR_INVALID_ARG, "packed blocks must be 8-byte aligned");
+    int64_t s_off = 0, f_off = 0, blk = 0;
+    int rc = rag_pack_layout(nq, k, &s_off, &f_off, &blk);
+    if (rc) return rc;
+    char* pack = static_cast<char*>(pack_dev);
+    float* pack_s = reinterpret_cast<float*>(pack + s_off);
+    long long* pack_i = reinterpret_cast<long long*>(pack);
+    uint32_t* pack_f = reinterpret_cast<uint32_t*>(pack + f_off);
+    rc = ivf_check_args(h, queries_dev, nq, k, nprobe, pack_s, pack_i);
+    if (rc) return rc;
+    if (ragc_comm_device(c) != h->device) return fail(RAG_ERR_INVALID_ARG, "communicator lives on device %d, the index on %d", ragc_comm_device(c), h->device);
+    const int world = ragc_comm_world(c);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t cst = comm_stream ? (hipStream_t)comm_stream : st;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        HIP_TRY(hipMemsetAsync(pack_f, 0, sizeof(uint32_t), st));   // this rank's list is final
+        rc = ivf_search_locked(h, queries_dev, nq, k, nprobe, pack_s, pack_i, st);   // (records h->ws_event on st when it returns)
+        if (rc) return rc;
+        if (cst != st) HIP_TRY(hipStreamWaitEvent(cst, h->ws_event, 0));
+        rc = ragc_comm_all_gather(c, pack_dev, gathered_dev, (size_t)blk, cst);
+        if (rc) return rc;
+    }
+    return rag_merge_topk_packed_flagged_device(h->device, h->metric, world, nq, k, gathered_dev, blk, s_off, f_off, out_scores_dev,
+                                                out_ids_dev, any_flag_dev, host_mirror, (void*)cst);
+}

@@ -110,6 +110,14 @@ class FlatIndex:
             self._handle(), C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(out_scores_ptr), C.c_void_p(out_ids_ptr),
             int(mode), C.c_void_p(flag_ptr or None), C.c_void_p(stream)))
 
+    def search_gather_device(self, comm: C.c_void_p, q_ptr: int, nq: int, k: int, mode: int, c_args: tuple, stream: int,
+                             comm_stream: int | None) -> None:
+        """The whole shard step as ONE call (rag_index_search_gather_device): local search -> all-gather on `comm` ->
+        flagged merge.  `c_args`: the slot's (pack, gathered, out_scores, out_ids, any_flag, host_mirror) pointers."""
+        _native.check(self._lib.rag_index_search_gather_device(
+            self._handle(), comm, C.c_void_p(q_ptr), int(nq), int(k), int(mode), *c_args, C.c_void_p(stream),
+            C.c_void_p(comm_stream) if comm_stream is not None else None))
+
     def search_from_device(self, q_ptr: int, nq: int, k: int, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
         """(D, I) on the host for queries that are already in device memory (an embedder's device-resident
         result on `stream`): rag_index_search_device_host_out — one read-back per array, one sync."""

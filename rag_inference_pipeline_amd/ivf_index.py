@@ -107,3 +107,13 @@ class IVFFlatIndex:
             self._h, C.c_void_p(q_ptr), int(nq), int(k), int(nprobe if nprobe is not None else self.nprobe),
             D.ctypes.data_as(C.POINTER(C.c_float)), I.ctypes.data_as(C.POINTER(C.c_int64)), C.c_void_p(stream)))
         return D, I
+
+    def search_gather_device(self, comm: C.c_void_p, q_ptr: int, nq: int, k: int, mode: int, c_args: tuple, stream: int,
+                             comm_stream: int | None) -> None:
+        """The shard step of a sharded IVF index as ONE call (rag_ivf_search_gather_device): local nprobe search ->
+        all-gather on `comm` -> merge.  `mode` (the flat index's fallback choice) has no meaning here: the list is final."""
+        if not self._h:
+            raise RuntimeError("IVFFlatIndex is closed")
+        _native.check(self._lib.rag_ivf_search_gather_device(
+            self._h, comm, C.c_void_p(q_ptr), int(nq), int(k), int(self.nprobe), *c_args, C.c_void_p(stream),
+            C.c_void_p(comm_stream) if comm_stream is not None else None))

@@ -192,7 +192,7 @@ class ShardedFlatIndex:
         self._req_comm: C.c_void_p | None = None   # overlap_collective: requests on a communicator and stream of their own
         self._req_stream = None
         self._head_mirror = None      # followers: pinned [head x 4 | seq] the request's last kernel posts
-        if on_gpu and self.backend == "nccl" and merge is None and hasattr(local, "_handle") \
+        if on_gpu and self.backend == "nccl" and merge is None and hasattr(local, "search_gather_device") \
                 and os.environ.get("RAG_AMD_OWN_RCCL", "1") != "0":
             self._comm = self._create_comm()
             if self._comm is not None:
@@ -345,11 +345,9 @@ class ShardedFlatIndex:
             self._local_search(s, queries, mode)
             self._gather_and_merge(s)
             return
-        from . import _native
         cs = self._comm_stream
-        _native.check(_native.lib().rag_index_search_gather_device(
-            self.local._handle(), self._comm, C.c_void_p(queries.data_ptr()), s.nq, s.k, int(mode), *s.c_args,
-            C.c_void_p(self._stream()), C.c_void_p(cs.cuda_stream) if cs is not None else None))
+        self.local.search_gather_device(self._comm, queries.data_ptr(), s.nq, s.k, int(mode), s.c_args, self._stream(),
+                                        cs.cuda_stream if cs is not None else None)
         if cs is not None:
             s.event.record(cs)
         else:

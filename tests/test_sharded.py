@@ -200,6 +200,43 @@ def test_sharded_search_over_rccl(gpu_required, tmp_path, world, metric, k, own)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", _nccl_worlds())
+@pytest.mark.parametrize("metric,k,own", [(1, 10, "1"), (0, 100, "1"), (1, 10, "0")])
+def test_sharded_ivf_search_over_rccl(gpu_required, tmp_path, world, metric, k, own):
+    """A sharded IVFFlat index in the nprobe mode over backend "nccl": every rank holds its share of every list; own = "1":
+    the step — local nprobe search (two-stage), ncclAllGather on the library's own communicator, merge — is ONE C-ABI
+    call (rag_ivf_search_gather_device), also with the collective on a second stream and through the leader / follower
+    protocol; own = "0": torch's collectives.  The unsharded oracle's ids and score bits either way."""
+    sys.path.insert(0, HERE)
+    from _sharded_ivf_worker import build_lists
+    n, d, nlist, nprobe = 40_000, 128, 200, 9
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        out = str(tmp_path / f"ivfrccl{r}.npz")
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(HERE, "_sharded_ivf_worker.py"), str(r), str(world), str(port), out, str(n), str(d), str(nlist),
+             str(nprobe), str(k), str(metric)],
+            env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", RAG_AMD_OWN_RCCL=own)))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lists, Q = build_lists(n, d, nlist, metric, nprobe)
+    Dw, Iw = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, nprobe, metric)
+    Dr, Ir = Dw[::-1], Iw[::-1]
+    for o in outs:
+        res = np.load(o)
+        assert int(res["own"]) == int(own) and int(res["two_stage"]) == 1
+        for a, (Dx, Ix) in (("", (Dw, Iw)), ("4", (Dw, Iw)), ("5", (Dr, Ir))):
+            np.testing.assert_array_equal(res["I" + a], Ix)
+            np.testing.assert_array_equal(res["D" + a], Dx)
+    lead = np.load(outs[0])
+    np.testing.assert_array_equal(lead["I3"], Iw[:5])
+    np.testing.assert_array_equal(lead["D3"], Dw[:5])
+    assert all(int(np.load(o)["served"]) == 1 for o in outs[1:])
+
+
+@pytest.mark.gpu
 def test_faiss_store_sharded_serving_mode(gpu_required, tmp_path):
     """FAISSStore under torch.distributed: every rank loads its row range of the same file, rank 0
     serves search() as usual, the other ranks follow until it unloads."""
