@@ -183,13 +183,16 @@ struct ScanParams {
     int dyn_tile0;           // first tile of the dynamic region = n_full * grid * NW
     int n_dyn_groups;        // tickets [0, n_dyn_groups): whole NW-tile groups; then n_singles tickets of one tile each
     int n_singles;
-    // MAP == true only: the tile walk goes over map[0 .. *map_count) (entry v for wave v % NW of workgroup v / NW % grid,
-    // round-robin), candidates only for the queries in an entry's mask and never rows whose map_ids word is 0xFFFFFFFF
+    // MAP == true only: the tile walk goes over map[0 .. *map_count) — item g = entries [NW g, NW g + NW), entry w for wave w;
+    // the first two items of a workgroup by formula, the rest by ticket — candidates only for the queries in an entry's mask
+    // and never rows whose map_ids word is 0xFFFFFFFF
     const TileMapEntry* map;
     const uint32_t* map_count;
     const uint32_t* map_ids;   // [rows] (padding rows of the list layout)
     uint32_t* map_thr;         // null, or [kQT * 32] band edges shared by the workgroups (ord32, 0 = none; a 128-byte line per
                                // query): see "shared band edges" in the kernel
+    uint32_t* map_ticket;      // the deal's ticket counter (0 at launch; the last workgroup to leave zeroes it again)
+    uint32_t* map_done;        // workgroups that have left (same)
 #ifdef RAGK_STAMPS
     unsigned long long* stamps;  // experiment build: [grid][8] s_memrealtime stamps (100 MHz) of workgroup phases
 #endif
@@ -206,6 +209,8 @@ struct ScanParams {
 __host__ __device__ inline size_t scan_lds_bytes(int d8, int C) {  // d8 = columns held in LDS (one chunk)
     return (size_t)d8 * 128 + (size_t)kQT * C * 8 + kQT * 4 + kQT * 4 + 16 + kQT * 4 + 2 * kQT * 4 + 16;  // + ticket word
 }
+// MAP mode: + the deal's item records (2 x 8 entries of two words) and their sequence word
+__host__ __device__ inline size_t scan_lds_bytes_map(int d8, int C) { return scan_lds_bytes(d8, C) + 144; }
 
 // NW = waves per workgroup (NW/4 per SIMD), E = buffer capacity / 64, D = register ring depth
 // (steps of 32 bytes per row in flight per wave), L2 = metric.
@@ -281,22 +286,32 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // The first ring loads go out in the middle of the prologue — after the query loads, before their LDS
     // stores.  Loads return in issue order: behind the ring's first touch of HBM (every CU at once) the
     // query fragments, all L2 hits, would wait for it; ahead of it they are stored while it is in flight.
-    // MAP: the walk goes over the tile map, round-robin (no tickets); an entry past the end is "no tile"
-    uint32_t map_n = 0u, qmask = 0xFFFFFFFFu, map_seen = 0u;
-    int map_iters = 0;
-    auto map_entry = [&](int it) -> TileMapEntry {
-        const uint32_t v = (uint32_t)blockIdx.x * kScanWaves + wave + (uint32_t)it * tiles_per_iter;
+    // MAP: the walk goes over the tile map.  Item g = entries [NW g, NW g + NW).  Iteration 0 of workgroup b takes item b
+    // (every wave reads its own entry), iteration 1 item grid + b, every later one the item of a TICKET (item = ticket +
+    // 2 grid).  Lanes 0 .. NW-1 of wave 0 run a three-deep pipeline at the TOP of each iteration — post the entries fetched an
+    // iteration ago (for iteration it + 1) into LDS, fetch the entries of the ticket drawn an iteration ago (it + 2), draw the
+    // next ticket (it + 3; lane 0) — so every returning memory operation has a whole tile time before its result is used
+    // (ivf_kernels.hip.h, ivf_batch_scan_kernel: the same deal).  An entry past the end is "no tile".
+    uint32_t map_n = 0u, qmask = 0xFFFFFFFFu, map_seen = 0u, map_gpend = 0u;
+    TileMapEntry map_pend{(uint32_t)p.n_tiles, 0u};
+    volatile uint32_t* mapw = tickw + 4;   // [2][NW][2] entries, then the newest iteration whose item is posted
+    const bool dealer = MAP && wave == 0 && lane < kScanWaves;
+    auto map_fetch = [&](uint32_t item, int w) -> TileMapEntry {   // entry w of `item`
+        const uint32_t v = item * kScanWaves + (uint32_t)w;
         TileMapEntry e{(uint32_t)p.n_tiles, 0u};
-        if (v < map_n) e = p.map[v];
+        if (item < 0x08000000u && v < map_n) e = p.map[v];
         return e;
     };
     int tile;
     if constexpr (MAP) {
         map_n = *p.map_count;
-        map_iters = (int)((map_n + (uint32_t)tiles_per_iter - 1u) / (uint32_t)tiles_per_iter);
-        const TileMapEntry e0 = map_entry(0);
+        const TileMapEntry e0 = map_fetch(blockIdx.x, wave);
         tile = __builtin_amdgcn_readfirstlane((int)e0.tile);
         qmask = __builtin_amdgcn_readfirstlane(e0.mask);
+        if (dealer) {
+            map_pend = map_fetch(gridDim.x + blockIdx.x, lane);
+            if (lane == 0) map_gpend = atomicAdd(p.map_ticket, 1u);
+        }
     } else {
         tile = tile_of(0);
     }
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     }
     if (tid < 4) flag[tid] = 0;
     if (tid == 0) tickw[1] = 0u;  // no iteration has this number: tickets are for iterations >= n_full >= 4
+    if (MAP && tid == 0) mapw[4 * kScanWaves] = 0u;   // (items are posted for iterations >= 1)
     __syncthreads();
     RAGK_STAMP(1);
 
@@ -491,12 +507,20 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
     // still reading that pass's flag.
     uint32_t seq = 0;
     const bool dyn = p.dyn_ctr != nullptr;  // kernel-uniform; then n_iters == n_full: the static rounds
-    bool more = (MAP ? map_iters : p.n_iters) > 0;   // workgroup-uniform: iteration `it` exists
+    bool more = MAP ? (uint32_t)blockIdx.x * kScanWaves < map_n : p.n_iters > 0;   // workgroup-uniform: iteration `it` exists
     for (int it = 0; more; ++it) {
         const bool active = tile < p.n_tiles;  // wave-uniform
-        TileMapEntry ent_n{(uint32_t)p.n_tiles, 0u};
+        uint32_t qmask_n = 0u;
         if constexpr (MAP) {
-            ent_n = map_entry(it + 1);   // requested here, used behind the K loop
+            if (dealer) {   // the deal (see the walk above)
+                volatile uint32_t* w = mapw + 2 * kScanWaves * ((it + 1) & 1);
+                w[2 * lane] = map_pend.tile;
+                w[2 * lane + 1] = map_pend.mask;
+                if (lane == 0) mapw[4 * kScanWaves] = (uint32_t)(it + 1);   // (a wave's LDS writes complete in order)
+                const uint32_t g = __builtin_amdgcn_readfirstlane(map_gpend);
+                map_pend = map_fetch(g + 2u * gridDim.x, lane);
+                if (lane == 0) map_gpend = atomicAdd(p.map_ticket, 1u);
+            }
             // Shared band edges.  A workgroup meets a given query in one or two of its items, so a filter that learns only
             // from its own rows stays cold (sort after sort).  The lower edge of a band — a k-th best approximate score
             // minus the margin — established by ANY workgroup bounds the final band from below (that workgroup's k-th
@@ -558,8 +582,12 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         int tnext = p.n_tiles;
         bool more_next;
         if constexpr (MAP) {
-            more_next = it + 1 < map_iters;
-            tnext = __builtin_amdgcn_readfirstlane((int)ent_n.tile);
+            while (mapw[4 * kScanWaves] != (uint32_t)(it + 1)) {
+            }
+            volatile uint32_t* w = mapw + 2 * kScanWaves * ((it + 1) & 1);
+            tnext = __builtin_amdgcn_readfirstlane((int)w[2 * wave]);
+            qmask_n = __builtin_amdgcn_readfirstlane(w[2 * wave + 1]);
+            more_next = __builtin_amdgcn_readfirstlane((int)w[0]) < p.n_tiles;
         } else if (!dyn || it + 1 < p.n_iters) {
             more_next = it + 1 < p.n_iters;
             if (more_next) tnext = tile_of(it + 1);
@@ -814,7 +842,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         if (it == 0) RAGK_STAMP(2);
         tile = tnext;
         more = more_next;
-        if constexpr (MAP) qmask = __builtin_amdgcn_readfirstlane(ent_n.mask);
+        if constexpr (MAP) qmask = qmask_n;
     }
 
     if (p.acc_out) return;
@@ -852,6 +880,13 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         }
     }
     RAGK_STAMP(4);
+    if constexpr (MAP) {   // the last workgroup to leave puts the ticket counter back (launches of an index are stream-ordered)
+        __syncthreads();
+        if (tid == 0 && atomicAdd(p.map_done, 1u) == gridDim.x - 1) {
+            *p.map_ticket = 0u;
+            *p.map_done = 0u;
+        }
+    }
 }
 
 // ---- sample pass -> starting thresholds ----------------------------------------------------------

@@ -520,7 +520,7 @@ int search_round(rag_index* h, const float* q_dev, int nq, int k, const ragk::u6
         sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
         sp.map = nullptr;
         sp.map_count = sp.map_ids = nullptr;
-        sp.map_thr = nullptr;
+        sp.map_thr = sp.map_ticket = sp.map_done = nullptr;
 #ifdef RAGK_STAMPS
         if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
         sp.stamps = enable ? nullptr : g_stamps;
@@ -688,7 +688,7 @@ int search_screened_block(rag_index* h, const float* qp, int nb, int k, float* o
     sp.dyn_tile0 = sp.n_dyn_groups = sp.n_singles = 0;
     sp.map = nullptr;
     sp.map_count = sp.map_ids = nullptr;
-    sp.map_thr = nullptr;
+    sp.map_thr = sp.map_ticket = sp.map_done = nullptr;
 #ifdef RAGK_STAMPS
     if (!g_stamps) (void)hipMalloc(reinterpret_cast<void**>(&g_stamps), 2048 * 8 * sizeof(unsigned long long));
     sp.stamps = g_stamps;

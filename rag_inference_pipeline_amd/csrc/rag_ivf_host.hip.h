@@ -301,7 +301,9 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
     const bool share_thr = env_int("RAG_AMD_IVF_SHARED_THRESHOLDS", 1) != 0;   // (experiment switch; results do not depend on it)
     // two-stage when the fp16 copy is valid and k is inside what the screening pass and ONE exact fallback round cover
     const bool two_stage = h->two_stage && h->rows_padded > 0 && k <= kScreenMaxK && k <= kmax && h->d8 <= 1024 &&
-                           screen_capacity(h->rowsidx->d64, k) > 0 && env_int("RAG_AMD_IVF_TWO_STAGE", 1) != 0;
+                           screen_capacity(h->rowsidx->d64, k) > 0 &&
+                           scan_lds_bytes_map(h->rowsidx->d64 / 2, screen_capacity(h->rowsidx->d64, k)) <= 160 * 1024 &&
+                           env_int("RAG_AMD_IVF_TWO_STAGE", 1) != 0;
     const int S = h->d8 / 8;
     const int ring = S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 1);
     for (int b0 = 0; b0 < nq; b0 += kQT) {
@@ -352,9 +354,11 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             sp.map_count = h->words;
             sp.map_ids = h->ids;
             sp.map_thr = share_thr ? h->words + 32 + kQT * kIvfThrStride : nullptr;
+            sp.map_ticket = h->words + 1;   // (the exact scan's counters: the two kernels of a pass run one after the other)
+            sp.map_done = h->words + 2;
             const int S16 = R->d64 / 16;
             ScanFn fn = screen_map_fn(cap, S16 % 8 == 0 ? 8 : 4, l2);
-            const size_t lds = scan_lds_bytes(R->d64 / 2, cap);
+            const size_t lds = scan_lds_bytes_map(R->d64 / 2, cap);
             if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
             HIP_TRY(hipGetLastError());
