@@ -186,19 +186,27 @@ __device__ __forceinline__ void fold_reversed(u64 (&a)[E], const u64 (&b)[E], in
     }
 }
 
-template <int E>
-__global__ __launch_bounds__(256) void ivf_coarse_select_kernel(const float* acc, const float* cnorm, const float* qnorm, int nlist,
-                                                               int np, int l2, long long* probe) {
+// NWV waves per workgroup (8 from 2048 keys up).  The kernel also computes the query's canonical ||q||^2 when asked to
+// (Q, qnorm_out != null: one lane of wave 1, while wave 0 folds the waves' lists — a separate 9 us launch otherwise) and
+// applies the dead-query rule with it at the end (every distance inf or NaN: no list is "nearest").
+template <int E, int NWV>
+__global__ __launch_bounds__(64 * NWV) void ivf_coarse_select_kernel(const float* acc, const float* cnorm, const float* qnorm_in,
+                                                                    const float* Q, int d, float* qnorm_out, int nlist, int np,
+                                                                    int l2, long long* probe) {
     constexpr int NB = 8 / E;      // chunks in flight per wave
     constexpr int CH = 64 * E;     // keys per chunk
-    __shared__ u64 tops[4][CH];
+    __shared__ u64 tops[NWV][CH];
+    __shared__ float s_qn;
+    extern __shared__ __attribute__((aligned(16))) char ivf_smem[];
+    float* qrow = reinterpret_cast<float*>(ivf_smem);   // [d8] (only when the norm is computed here)
     const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float t0 = RAGK_SCORE_FLOOR;
-    if (l2 && !(qnorm[q] <= 3.402823466e+38f)) t0 = __builtin_nanf("");   // every distance inf or NaN: no list is "nearest"
+    const int d8 = (d + 7) & ~7;
+    if (qnorm_out)
+        for (int c = threadIdx.x; c < d8; c += 64 * NWV) qrow[c] = c < d ? Q[(size_t)q * d + c] : 0.f;
     u64 top[1][E];
 #pragma unroll
     for (int e = 0; e < E; ++e) top[0][e] = 0ull;
-    for (int base = wave * NB * CH; base < nlist; base += 4 * NB * CH) {
+    for (int base = wave * NB * CH; base < nlist; base += NWV * NB * CH) {
         u64 c[NB][E];
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(256) void ivf_coarse_select_kernel(const float* acc
                 if (row < nlist) {
                     const float a = acc[(size_t)row * kQT + q];
                     const float sc = l2 ? __builtin_fmaf(2.0f, a, -cnorm[row]) + 0.0f : a + 0.0f;
-                    if (sc >= t0) key = make_key(sc, (uint32_t)row);
+                    if (sc >= RAGK_SCORE_FLOOR) key = make_key(sc, (uint32_t)row);
                 }
                 c[s][e] = key;
             }
@@ -228,16 +236,36 @@ __global__ __launch_bounds__(256) void ivf_coarse_select_kernel(const float* acc
 #pragma unroll
     for (int e = 0; e < E; ++e) tops[wave][e * 64 + lane] = top[0][e];
     __syncthreads();
-    if (wave != 0) return;
-    for (int w = 1; w < 4; ++w) {
+    if (wave == 0) {
+        for (int w = 1; w < NWV; ++w) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) top[0][e] = umax64(top[0][e], tops[w][(E - 1 - e) * 64 + 63 - lane]);
-        wave_merge_desc<E, 1>(top, lane, 1);
+            for (int e = 0; e < E; ++e) top[0][e] = umax64(top[0][e], tops[w][(E - 1 - e) * 64 + 63 - lane]);
+            wave_merge_desc<E, 1>(top, lane, 1);
+        }
+    } else if (wave == 1 && lane == 0) {
+        float qn = qnorm_in ? qnorm_in[q] : 0.f;
+        if (qnorm_out) {   // the canonical chain (flat_kernels.hip.h query_sqnorm_kernel: the same bits)
+            float a = 0.f;
+            for (int s = 0; s < d8; s += 8) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(qrow + s), x1 = *reinterpret_cast<const f32x4*>(qrow + s + 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a = __builtin_fmaf(x0[t], x0[t], a);
+                    a = __builtin_fmaf(x1[t], x1[t], a);
+                }
+            }
+            qn = a;
+            qnorm_out[q] = a;
+        }
+        s_qn = qn;
     }
+    __syncthreads();
+    if (wave != 0) return;
+    const bool dead = l2 && !(s_qn <= 3.402823466e+38f);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int j = e * 64 + lane;
-        if (j < np) probe[(size_t)q * np + j] = top[0][e] ? (long long)(0xFFFFFFFFu - (uint32_t)top[0][e]) : -1ll;
+        if (j < np) probe[(size_t)q * np + j] = (top[0][e] && !dead) ? (long long)(0xFFFFFFFFu - (uint32_t)top[0][e]) : -1ll;
     }
 }
 

@@ -247,7 +247,8 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
     if (k > kmax && !h->round_keys && (rc = dev_alloc(&h->round_keys, (size_t)2 * kQT))) return rc;
     const bool l2 = h->metric == RAG_METRIC_L2;
     const bool cl2 = h->coarse->metric == RAG_METRIC_L2;
-    if (l2 || cl2) {
+    const bool need_qn = l2 || cl2;
+    if (need_qn && np > 256) {   // (up to 256 probes the selection kernel computes the norms itself)
         query_sqnorm_kernel<<<dim3(nq), dim3(64), (size_t)h->d8 * sizeof(float), st>>>(q_dev, h->d, h->qnorm);
         HIP_TRY(hipGetLastError());
     }
@@ -286,12 +287,14 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
             HIP_TRY(hipGetLastError());
             long long* pr = h->probe + (size_t)b0 * np;
-            if (np <= 64)
-                ivf_coarse_select_kernel<1><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
-            else if (np <= 128)
-                ivf_coarse_select_kernel<2><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
-            else
-                ivf_coarse_select_kernel<4><<<dim3(nb), dim3(256), 0, st>>>(h->c_acc, c->xnorm, h->qnorm + b0, (int)c->n, np, cl2 ? 1 : 0, pr);
+            using SelFn = void (*)(const float*, const float*, const float*, const float*, int, float*, int, int, int, long long*);
+            const bool wide = c->n >= 2048;   // 8 waves per query from 2048 lists up
+            SelFn sel = np <= 64 ? (wide ? (SelFn)ivf_coarse_select_kernel<1, 8> : (SelFn)ivf_coarse_select_kernel<1, 4>)
+                        : np <= 128 ? (wide ? (SelFn)ivf_coarse_select_kernel<2, 8> : (SelFn)ivf_coarse_select_kernel<2, 4>)
+                                    : (wide ? (SelFn)ivf_coarse_select_kernel<4, 8> : (SelFn)ivf_coarse_select_kernel<4, 4>);
+            hipLaunchKernelGGL(sel, dim3(nb), dim3(wide ? 512 : 256), need_qn ? (size_t)h->d8 * sizeof(float) : 0, st, h->c_acc, c->xnorm,
+                               (const float*)nullptr, q_dev + (size_t)b0 * h->d, h->d, need_qn ? h->qnorm + b0 : (float*)nullptr, (int)c->n, np,
+                               cl2 ? 1 : 0, pr);
             HIP_TRY(hipGetLastError());
         }
     } else {
