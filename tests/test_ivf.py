@@ -305,6 +305,51 @@ def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
 
 
 @pytest.mark.gpu
+def test_concurrent_host_searches_share_one_handle(gpu_required, tmp_path):
+    """The reference's scheduler runs batches on pool threads (gateway/batch_scheduler.py:286-288): four threads search one
+    IVFFlatIndex at once, host pointers and device pointers mixed, shapes mixed — every result is the oracle's."""
+    import threading
+    import torch
+    from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
+    n, d, nlist = 40_000, 192, 128
+    X, path = _file(tmp_path, n, d, nlist, 1, seed=13)
+    lists = index_io.read_ivfflat_lists(path)
+    idx = IVFFlatIndex(lists, nprobe=6)
+    errors = []
+
+    def client(t: int) -> None:
+        try:
+            rng = np.random.default_rng(500 + t)
+            stream = torch.cuda.Stream()
+            for it in range(6):
+                nq, k = ((32, 10), (3, 100), (1, 5), (40, 10))[(t + it) % 4]
+                Q = _unit(rng, nq, d)
+                if (t + it) % 2:
+                    D, I = idx.search(Q, k)
+                else:
+                    with torch.cuda.stream(stream):
+                        q = torch.from_numpy(Q).cuda()
+                        s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+                        i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+                        idx.search_device(q.data_ptr(), nq, k, s.data_ptr(), i.data_ptr(), stream.cuda_stream)
+                    stream.synchronize()
+                    D, I = s.cpu().numpy(), i.cpu().numpy()
+                Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, k, 6, 1)
+                if not (np.array_equal(I, Io) and np.array_equal(D.view(np.uint32), Do.view(np.uint32))):
+                    errors.append(f"thread {t} round {it}: differs")
+        except Exception as exc:  # noqa: BLE001
+            errors.append(f"thread {t}: {type(exc).__name__}: {exc}")
+
+    pool = [threading.Thread(target=client, args=(t,)) for t in range(4)]
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    idx.close()
+    assert not errors, errors
+
+
+@pytest.mark.gpu
 def test_hip_nprobe_search_with_the_most_lists_the_mode_takes(gpu_required):
     """nlist = 32768 (the plan kernel's 128 KB of list masks in LDS): lists of a row or two, most of them one tile; one more
     list is refused."""
