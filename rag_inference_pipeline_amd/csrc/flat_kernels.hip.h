@@ -498,8 +498,7 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
 
     const u64 key_ceil = p.ceil ? p.ceil[r] : ~0ull;
     // Warm start (k <= 16, 8-wave build, no sampled threshold): see the filter below.
-    // (not in MAP mode: a list layout's padding rows — zero vectors, the best possible L2 score — would count as rows)
-    const bool warm = !MAP && kScanWaves == 8 && p.k <= 16 && !p.acc_out && p.thr_key == nullptr;
+    const bool warm = kScanWaves == 8 && p.k <= 16 && !p.acc_out && p.thr_key == nullptr;
 
     // Overflow flags: pass number seq (one pass = one trip through the barrier loop below) owns
     // flag[seq & 3]; appends raise the flag of the pass that will check them, and pass seq clears
@@ -676,11 +675,14 @@ __global__ __launch_bounds__(NW * 64) void scan_topk_kernel(const ScanParams p) 
         if (warm && it == 0) {  // kernel-uniform
             float* sub = reinterpret_cast<float*>(keys);  // the candidate buffers are still empty
             float m = -__builtin_inff();
-            if (active) {
+            if (active && (!MAP || ((qmask >> r) & 1u))) {   // (MAP: only tiles of lists the query probes ...)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const long long row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil) m = fmaxf(m, sc[i]);  // NaN never wins
+                    bool real = row <= last_row && make_key(sc[i], (uint32_t)row) < key_ceil;
+                    // (... and never a list layout's padding row: the zero vector has the best possible L2 score)
+                    if constexpr (MAP) real = real && p.map_ids[row] != 0xFFFFFFFFu;
+                    if (real) m = fmaxf(m, sc[i]);  // NaN never wins
                 }
             }
             sub[r * 16 + wave * 2 + h] = m;
