@@ -13,6 +13,7 @@ struct rag_ivf {
     float* X = nullptr;               // = rowsidx->X: d8 columns
     float* xnorm = nullptr;           // = rowsidx->xnorm (L2)
     bool two_stage = false;           // the fp16 copy exists and covers the corpus (rag_index_set_screening on rowsidx)
+    uint32_t* fb_pin = nullptr;       // pinned: the two-stage search's any_fallback word, read back with the results (host entry points)
     uint32_t* ids = nullptr;          // kIvfPadId on padding rows
     uint32_t* tile_off = nullptr;     // nlist + 1: first tile of each list
     hipStream_t stream = nullptr;     // the host-pointer entry point's stream
@@ -93,6 +94,7 @@ extern "C" int rag_ivf_destroy(rag_ivf* h) {
             if (p) (void)hipFree(p);
         if (h->stream) (void)hipStreamDestroy(h->stream);
         if (h->ws_event) (void)hipEventDestroy(h->ws_event);
+        if (h->fb_pin) (void)hipHostFree(h->fb_pin);
     }
     rag_index_destroy(h->coarse);
     rag_index_destroy(h->rowsidx);   // X, xnorm, the fp16 copy
@@ -217,8 +219,48 @@ int ivf_max_k(int d8) {
     return best;
 }
 
-// the whole search on `st`, device pointers
-int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe, float* out_s, long long* out_i, hipStream_t st) {
+// The exact list scan of one pass (<= 32 queries) over the plan's tiles, k in rounds, and the merge of the workgroups' lists.
+// `enable` / `qmask` / `epoch`: as the two-stage search's fallback (no-op launches unless *enable == epoch, then only the
+// queries whose qmask word equals epoch are rewritten); null / 0: the search itself.
+int ivf_exact_pass(rag_ivf* h, const float* q_pass, const float* qnorm_pass, int nb, int k, float* out_s, long long* out_i,
+                   hipStream_t st, const uint32_t* enable, const uint32_t* qmask, uint32_t epoch) {
+    using namespace ragk;
+    const int kmax = ivf_max_k(h->d8);
+    const int grid = std::max(1, h->n_cus);
+    const bool l2 = h->metric == RAG_METRIC_L2;
+    const bool share_thr = env_int("RAG_AMD_IVF_SHARED_THRESHOLDS", 1) != 0;   // (experiment switch; results do not depend on it)
+    const int S = h->d8 / 8;
+    const int ring = S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 1);
+    int rc, done = 0, flip = 0;
+    while (done < k) {
+        const int kr = std::min(kmax, k - done);
+        const int cap = ivf_capacity(h->d8, kr);
+        const u64* ceil = done ? h->round_keys + (size_t)flip * kQT : nullptr;
+        u64* last = k > kmax ? h->round_keys + (size_t)(flip ^ 1) * kQT : nullptr;
+        IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_pass, qnorm_pass, h->tiles, h->words, h->words + 1, h->words + 2, h->partial,
+                          ceil, enable, epoch, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr, l2 ? 1 : 0};
+        if (done) HIP_TRY(hipMemsetAsync(h->words + 32, 0, kQT * kIvfThrStride * sizeof(uint32_t), st));   // a round's thresholds bind that round's candidates only
+        IvfScanFn fn = ivf_scan_fn(cap, ring);
+        const size_t lds = ivf_scan_lds_bytes(h->d8, cap);
+        if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
+        HIP_TRY(hipGetLastError());
+        KeyListSrc src{h->partial, grid, kr};
+        MergeOut mo{out_s + done, out_i + done, last, k, qnorm_pass, 0, h->metric, 0, qmask, epoch};
+        launch_merge(src, grid, nb, kr, merge_look(grid, kr, kr), mo, st);
+        HIP_TRY(hipGetLastError());
+        done += kr;
+        flip ^= 1;
+    }
+    return RAG_OK;
+}
+
+// the whole search on `st`, device pointers.  `deferred_epoch` (host entry points, one pass): a two-stage search does not
+// enqueue its fallback launches; it hands back its epoch and the caller — who waits for the results anyway — reads
+// any_fallback with them and runs ivf_exact_pass only when a certificate failed (as rag_index_search does)
+int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe, float* out_s, long long* out_i, hipStream_t st,
+                      uint32_t* deferred_epoch = nullptr) {
+    if (deferred_epoch) *deferred_epoch = 0;
     using namespace ragk;
     if (h->ws_used && h->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, h->ws_event, 0));
     struct Mark {  // record the workspace hand-over point on every exit path
@@ -307,8 +349,6 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
                            screen_capacity(h->rowsidx->d64, k) > 0 &&
                            scan_lds_bytes_map(h->rowsidx->d64 / 2, screen_capacity(h->rowsidx->d64, k)) <= 160 * 1024 &&
                            env_int("RAG_AMD_IVF_TWO_STAGE", 1) != 0;
-    const int S = h->d8 / 8;
-    const int ring = S % 8 == 0 ? 8 : (S % 4 == 0 ? 4 : 1);
     for (int b0 = 0; b0 < nq; b0 += kQT) {
         const int nb = std::min(kQT, nq - b0);
         // step 2: this pass's probe table -> list masks -> work items
@@ -399,28 +439,13 @@ int ivf_search_locked(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe,
             fb_qmask = R->sq->fallback;
             fb_epoch = epoch;
         }
-        int done = 0, flip = 0;
-        while (done < k) {
-            const int kr = std::min(kmax, k - done);
-            const int cap = ivf_capacity(h->d8, kr);
-            const u64* ceil = done ? h->round_keys + (size_t)flip * kQT : nullptr;
-            u64* last = k > kmax ? h->round_keys + (size_t)(flip ^ 1) * kQT : nullptr;
-            IvfBatchParams sp{h->X, h->d8, h->xnorm, h->ids, q_dev + (size_t)b0 * h->d, h->qnorm + b0, h->tiles, h->words, h->words + 1,
-                              h->words + 2, h->partial, ceil, fb_enable, fb_epoch, share_thr ? h->words + 32 : nullptr, h->d, h->d8, nb, kr,
-                              l2 ? 1 : 0};
-            if (done) HIP_TRY(hipMemsetAsync(h->words + 32, 0, kQT * kIvfThrStride * sizeof(uint32_t), st));   // a round's thresholds bind that round's candidates only
-            IvfScanFn fn = ivf_scan_fn(cap, ring);
-            const size_t lds = ivf_scan_lds_bytes(h->d8, cap);
-            if ((rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), lds))) return rc;
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, sp);
-            HIP_TRY(hipGetLastError());
-            KeyListSrc src{h->partial, grid, kr};
-            MergeOut mo{out_s + (size_t)b0 * k + done, out_i + (size_t)b0 * k + done, last, k, h->qnorm + b0, 0, h->metric, 0, fb_qmask, fb_epoch};
-            launch_merge(src, grid, nb, kr, merge_look(grid, kr, kr), mo, st);
-            HIP_TRY(hipGetLastError());
-            done += kr;
-            flip ^= 1;
+        if (two_stage && deferred_epoch && nq <= kQT) {
+            *deferred_epoch = fb_epoch;
+            continue;
         }
+        if ((rc = ivf_exact_pass(h, q_dev + (size_t)b0 * h->d, h->qnorm + b0, nb, k, out_s + (size_t)b0 * k, out_i + (size_t)b0 * k, st,
+                                 fb_enable, fb_qmask, fb_epoch)))
+            return rc;
     }
     return RAG_OK;
 }
@@ -454,10 +479,19 @@ int ivf_search_to_host(rag_ivf* h, const float* q_dev, int nq, int k, int nprobe
         if ((rc = ivf_grow(&h->out_s, &cap2, (size_t)nq * k))) return rc;
         if ((rc = ivf_grow(&h->out_i, &h->out_cap, (size_t)nq * k))) return rc;
     }
-    if ((rc = ivf_search_locked(h, q_dev, nq, k, nprobe, h->out_s, h->out_i, st))) return rc;
+    uint32_t epoch = 0;
+    if ((rc = ivf_search_locked(h, q_dev, nq, k, nprobe, h->out_s, h->out_i, st, &epoch))) return rc;
+    if (epoch && !h->fb_pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->fb_pin), sizeof(uint32_t), hipHostMallocDefault));
+    if (epoch) HIP_TRY(hipMemcpyAsync(h->fb_pin, &h->rowsidx->sq->any_fallback, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_scores, h->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_ids, h->out_i, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (epoch && *h->fb_pin == epoch) {   // a certificate failed: the exact scan rewrites those queries (the plan's tiles are still in place)
+        if ((rc = ivf_exact_pass(h, q_dev, h->qnorm, nq, k, h->out_s, h->out_i, st, nullptr, h->rowsidx->sq->fallback, epoch))) return rc;
+        HIP_TRY(hipMemcpyAsync(out_scores, h->out_s, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_ids, h->out_i, (size_t)nq * k * sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return RAG_OK;
 }
 }  // namespace
