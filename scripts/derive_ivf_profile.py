@@ -57,7 +57,7 @@ def main() -> None:
     for extra in sys.argv[3:]:
         e = last_json(extra)
         out.setdefault("other_runs", []).append({k: e[k] for k in ("workload", "list_rows", "batches") if k in e}
-                                                | {k: e[k] for k in ("exhaustive_flat_ms_per_batch",) if k in e})
+                                                | {k: e[k] for k in ("exhaustive_flat_ms_per_batch", "exhaustive_flat_two_stage_ms_per_batch") if k in e})
     print(json.dumps(out, indent=1))
 
 
