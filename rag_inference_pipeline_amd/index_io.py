@@ -259,6 +259,44 @@ def write_ivfflat_index(path: str | os.PathLike, rows: np.ndarray, nlist: int, m
                 fh.write(m.tobytes())
 
 
+def write_ivfflat_file(path: str | os.PathLike, rows: np.ndarray, centroids: np.ndarray, assign: np.ndarray,
+                       metric: int = METRIC_L2, nprobe: int = 1, ids: np.ndarray | None = None) -> None:
+    """Write a FAISS-layout IndexIVFFlat file from rows, trained centroids and one list number per row (flat L2
+    quantizer, `full` list-size table, no direct map — what scripts/create_test_docs.py:83-104 produces with faiss).
+    Stored ids default to the row numbers; lists hold their rows in ascending row order.  Rows are streamed list by list."""
+    rows = np.asarray(rows, dtype=np.float32)
+    centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+    n, d = rows.shape
+    nlist = centroids.shape[0]
+    assign = np.asarray(assign, dtype=np.int64)
+    if centroids.shape[1] != d or assign.shape != (n,):
+        raise ValueError("rows, centroids and assign do not fit together")
+    ids = np.arange(n, dtype=np.int64) if ids is None else np.asarray(ids, dtype=np.int64)
+    metric_type = 0 if metric == METRIC_INNER_PRODUCT else 1
+    order = np.argsort(assign, kind="stable")
+    counts = np.bincount(assign, minlength=nlist) if n else np.zeros(nlist, dtype=np.int64)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    with open(path, "wb") as fh:
+        fh.write(b"IwFl")
+        fh.write(_HEADER.pack(d, n, 1 << 20, 1 << 20, 1, metric_type))
+        fh.write(struct.pack("<QQ", nlist, nprobe))
+        fh.write(b"IxF2")
+        fh.write(_HEADER.pack(d, nlist, 1 << 20, 1 << 20, 1, 1))
+        fh.write(struct.pack("<Q", nlist * d))
+        fh.write(centroids.tobytes())
+        fh.write(struct.pack("<BQ", 0, 0))  # no direct map
+        fh.write(b"ilar")
+        fh.write(struct.pack("<QQ", nlist, 4 * d))
+        fh.write(b"full")
+        fh.write(struct.pack("<Q", nlist))
+        fh.write(counts.astype(np.uint64).tobytes())
+        for l in range(nlist):
+            m = order[bounds[l]:bounds[l + 1]]
+            if len(m):
+                fh.write(np.ascontiguousarray(rows[m], dtype=np.float32).tobytes())
+                fh.write(ids[m].astype(np.int64).tobytes())
+
+
 def _read_faiss_flat(path: Path, mmap: bool) -> tuple[np.ndarray, int]:
     size = path.stat().st_size
     with path.open("rb") as fh:

@@ -94,6 +94,39 @@ def test_list_shards_partition_every_list_and_merge_to_the_unsharded_result(tmp_
         lists.shard(3, 3)
 
 
+def test_build_ivf_tool_writes_a_file_both_modes_can_load(tmp_path):
+    """tools/build_ivf.py (host side; the assignment injected — on a GPU box it is this build's flat search): k-means on a
+    sample, every row in exactly one list, the `IwFl` file read back as lists (nprobe mode) and as the original rows in their
+    original order (exhaustive mode); training moves the centroids towards the data (lower quantisation error than the
+    initial pick)."""
+    from rag_inference_pipeline_amd.tools.build_ivf import build_ivf, train_centroids
+    rng = np.random.default_rng(3)
+    centres = rng.standard_normal((12, 20)).astype(np.float32)
+    X = (centres[rng.integers(0, 12, size=4000)] + 0.1 * rng.standard_normal((4000, 20))).astype(np.float32)
+
+    def nearest(rows, cent):
+        return np.argmin((cent.astype(np.float64) ** 2).sum(1)[None, :] - 2.0 * rows.astype(np.float64) @ cent.astype(np.float64).T, axis=1)
+
+    def qerr(cent):
+        a = nearest(X, cent)
+        return float(((X - cent[a]) ** 2).sum())
+
+    assert qerr(train_centroids(X[:1000], 12, iters=25, seed=5)) < 0.7 * qerr(train_centroids(X[:1000], 12, iters=0, seed=5))
+    out = tmp_path / "built.ivf"
+    info = build_ivf(X, 12, 1, str(out), nprobe=3, train_rows=1000, iters=25, seed=5, assign=nearest)
+    assert info["rows"] == 4000 and info["nlist"] == 12 and info["nprobe"] == 3
+    lists = index_io.read_ivfflat_lists(out)
+    assert (lists.nlist, lists.ntotal, lists.nprobe, lists.metric, lists.quantizer_metric) == (12, 4000, 3, 1, 1)
+    np.testing.assert_array_equal(np.sort(lists.ids), np.arange(4000))
+    np.testing.assert_array_equal(lists.rows, X[lists.ids])
+    for l in range(12):   # every row sits in the list of its nearest centroid, lists in ascending id order
+        ids = lists.ids[lists.offsets[l]:lists.offsets[l + 1]]
+        assert (np.diff(ids) > 0).all() and (nearest(X[ids], lists.centroids) == l).all()
+    rows, metric = index_io.read_index_file(out, 0)
+    assert metric == 1
+    np.testing.assert_array_equal(rows, X)
+
+
 def test_settings_carry_the_ivf_mode(monkeypatch):
     from rag_inference_pipeline_amd.config import PipelineSettings
     assert PipelineSettings().faiss_ivf_mode == "exhaustive"
@@ -302,6 +335,41 @@ def test_ivf_error_contract_and_edge_cases(gpu_required, tmp_path):
     with pytest.raises(_native.RagAmdError, match="1024"):
         IVFFlatIndex(IVFFlatLists(np.zeros((2, 1032), np.float32), 1, np.zeros((0, 1032), np.float32), np.zeros(0, np.int64),
                                   np.zeros(3, np.int64), 1, 1))
+
+
+@pytest.mark.gpu
+def test_build_ivf_tool_on_the_gpu_and_search_what_it_built(gpu_required, tmp_path):
+    """The whole path without faiss: a flat index file -> tools/build_ivf.py (rows assigned by this build's flat search over
+    the trained centroids) -> FAISSStore in the nprobe mode.  A row's list is the first list its own vector probes, so every
+    row finds itself with nprobe = 1; results equal the oracle's on the file the tool wrote."""
+    from rag_inference_pipeline_amd.components.faiss_store import FAISSStore
+    from rag_inference_pipeline_amd.config import PipelineSettings
+    from rag_inference_pipeline_amd.tools.build_ivf import build_ivf
+    rng = np.random.default_rng(9)
+    n, d, nlist = 30_000, 96, 256
+    centres = _unit(rng, 300, d)
+    X = centres[rng.integers(0, 300, size=n)] + 0.3 * rng.standard_normal((n, d)).astype(np.float32) / np.sqrt(d)
+    X = np.ascontiguousarray(X / np.linalg.norm(X, axis=1, keepdims=True), dtype=np.float32)
+    flat = tmp_path / "corpus.npy"
+    np.save(flat, X)
+    out = tmp_path / "corpus.ivf"
+    info = build_ivf(X, nlist, 1, str(out), nprobe=8, train_rows=10_000, iters=10)
+    assert info["rows"] == n and info["empty_lists"] < nlist // 2
+    lists = index_io.read_ivfflat_lists(out)
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(out), faiss_dim=d, RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=1))
+    store.load()
+    probe = rng.choice(n, size=64, replace=False)
+    D, I = store.search(X[probe], 1)
+    np.testing.assert_array_equal(I[:, 0], probe)            # nprobe = 1: the row's own list is the one probed
+    store.unload()
+    store = FAISSStore(PipelineSettings(FAISS_INDEX_PATH=str(out), faiss_dim=d, RAG_AMD_IVF_MODE="nprobe", FAISS_NPROBE=8))
+    store.load()
+    Q = _unit(rng, 32, d)
+    D, I = store.search(Q, 10)
+    Do, Io = oracle.ivf_search(lists.centroids, lists.quantizer_metric, lists.rows, lists.ids, lists.offsets, Q, 10, 8, 1)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D.view(np.uint32), Do.view(np.uint32))
+    store.unload()
 
 
 @pytest.mark.gpu
