@@ -161,6 +161,9 @@ class FAISSStore:
                                              max_batch=max(1, int(getattr(self.settings, "retrieval_batch_size", 32))))
         self._is_loaded = True
         logger.info("Set FAISS nprobe=%d", min(nprobe, lists.nlist))
+        logger.info("IVF list scan: %s", "two-stage (fp16 screening pass + exact second stage, identical results)"
+                    if self._ivf.two_stage else "one-stage fp32 (RAG_AMD_IVF_TWO_STAGE=0, or the corpus is outside the "
+                                                "range the screening pass's error bound covers)")
         logger.info("FAISS index loaded successfully: %d vectors, dimension=%d (IVFFlat, %d lists; %d rows on this rank)",
                     lists.ntotal, lists.centroids.shape[1], lists.nlist, local.ntotal)
         if lists.ntotal:
