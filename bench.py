@@ -634,11 +634,28 @@ def main() -> None:
             import scripts.bench_ivf as bivf
 
             base = dict(n=4_500_000, d=768, nlist=4096, nprobe=64, k=k, steps=20, warmup=3, exhaustive=False, unit=False)
-            clustered = bivf.run(argparse.Namespace(**base, batches="1,32", clustered=True))
+            kept: dict = {}
+            clustered = bivf.run(argparse.Namespace(**base, batches="1,32", clustered=True), keep=kept)
+            ivf_cpu = None
+            if not args.no_cpu_baseline:
+                # the CPU path beside it: the oracle's restatement of the nprobe search (flat oracle over the centroids, then
+                # over each query's gathered lists; C + OpenMP) on ONE batch of 32 of the same queries
+                from oracle import flat as _oracle
+
+                lst, q32 = kept["lists"], kept["queries"]
+                avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                cores = max(1, min(16, avail, _oracle.num_threads()))   # the reference's faiss_threads policy, as the headline's baseline
+                t0 = time.perf_counter()
+                _oracle.ivf_search(lst.centroids, lst.quantizer_metric, lst.rows, lst.ids, lst.offsets, q32, k, 64, 1, nthreads=cores)
+                dt = time.perf_counter() - t0
+                ivf_cpu = {"value": len(q32) / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+                           "sample": f"oracle/flat.py:ivf_search, one batch of {len(q32)} queries on the clustered 4.5M x 768 lists "
+                                     f"({dt * 1e3:.0f} ms)"}
+            kept.clear()
             generator = bivf.run(argparse.Namespace(**base, batches="32", clustered=False))
             b32 = clustered["batches"]["32"]
             ach = b32["scan_bytes"] / b32["ms_per_batch"] / 1e6
-            ivf_leg = {"clustered_balanced_lists": clustered, "generator_gaussian_rows": generator,
+            ivf_leg = {"clustered_balanced_lists": clustered, "generator_gaussian_rows": generator, "cpu_baseline": ivf_cpu,
                        "roofline": {"bound": "hbm", "kernel": "scan_topk_kernel<P=1, MAP> fp16 screening pass over the probed lists (whole search timed: coarse "
                                     "quantizer, plan, screening pass, resolve, self-disabling exact fallback)", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": ach / HBM_PEAK_GBPS, "algorithmic_bytes_per_batch": b32["scan_bytes"],

@@ -104,7 +104,7 @@ def merge(scores_: np.ndarray, ids: np.ndarray, metric: int = METRIC_IP) -> tupl
 
 
 def ivf_search(centroids: np.ndarray, quantizer_metric: int, rows: np.ndarray, ids: np.ndarray, offsets: np.ndarray,
-               Q: np.ndarray, k: int, nprobe: int, metric: int = METRIC_L2) -> tuple[np.ndarray, np.ndarray]:
+               Q: np.ndarray, k: int, nprobe: int, metric: int = METRIC_L2, nthreads: int = 0) -> tuple[np.ndarray, np.ndarray]:
     """Oracle of the IVFFlat `nprobe` mode (faiss IndexIVF::search as the reference uses it: index.nprobe set at load,
     faiss_store.py:84-92; index.search, faiss_store.py:152; file written by scripts/create_test_docs.py:83-104).
       1. quantizer.search(Q, nprobe): the flat oracle over the centroids under the quantizer's metric;
@@ -116,7 +116,7 @@ def ivf_search(centroids: np.ndarray, quantizer_metric: int, rows: np.ndarray, i
     centroids, rows, Q = _f32(centroids), _f32(rows), _f32(Q)
     nlist = centroids.shape[0]
     nprobe = min(int(nprobe), nlist)
-    _, probe = search(centroids, Q, nprobe, quantizer_metric)
+    _, probe = search(centroids, Q, nprobe, quantizer_metric, nthreads=nthreads)
     D = np.full((Q.shape[0], k), np.finfo(np.float32).max if metric == METRIC_L2 else -np.finfo(np.float32).max,
                 dtype=np.float32)
     I = np.full((Q.shape[0], k), -1, dtype=np.int64)
@@ -125,7 +125,7 @@ def ivf_search(centroids: np.ndarray, quantizer_metric: int, rows: np.ndarray, i
         if sel.size == 0:
             continue
         sel = sel[np.argsort(ids[sel], kind="stable")]        # ascending stored id: the local row number then breaks
-        Dq, Iq = search(rows[sel], Q[qi:qi + 1], k, metric)   # ties exactly as the stored id would
+        Dq, Iq = search(rows[sel], Q[qi:qi + 1], k, metric, nthreads=nthreads)   # ties exactly as the stored id would
         ok = Iq[0] >= 0
         D[qi, ok] = Dq[0, ok]
         I[qi, ok] = ids[sel][Iq[0, ok]]

@@ -75,8 +75,10 @@ def build_lists(n: int, d: int, nlist: int, nprobe: int, unit: bool, clustered: 
     return lists, cent
 
 
-def run(a) -> dict:
-    """`a`: a namespace with n, d, nlist, nprobe, k, batches (comma list), steps, warmup, exhaustive, unit, clustered."""
+def run(a, keep: dict | None = None) -> dict:
+    """`a`: a namespace with n, d, nlist, nprobe, k, batches (comma list), steps, warmup, exhaustive, unit, clustered.
+    `keep` (a dict): receives the lists and the first query set of the last batch size (bench.py times its CPU baseline on
+    them)."""
     global _CENTERS
     _CENTERS = None
     from rag_inference_pipeline_amd.ivf_index import IVFFlatIndex
@@ -172,6 +174,9 @@ def run(a) -> dict:
         flat.close()
     idx.close()
     _CENTERS = None
+    if keep is not None:
+        keep["lists"] = lists
+        keep["queries"] = sets[0].cpu().numpy()
     del lists, cent
     torch.cuda.empty_cache()
     return out
